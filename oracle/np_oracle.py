@@ -1,0 +1,344 @@
+"""Second, independent restatement of the path in numpy (TEST INFRASTRUCTURE ONLY).
+
+PARITY UNPINNED.  Purpose: the C++ oracle (oracle/haar_oracle.cpp) must not
+be self-confirming.  This module restates the same OpenCV>=4 semantics for the call at
+reference src/tracker/detector.cc:25-31 with a *different structure*:
+  - dense evaluation of every grid position, all windows of a level at once (array ops),
+  - the x-skip through its closed form instead of the sequential loop,
+  - resize coefficients through exact rational arithmetic cross-checked against the f64 rule.
+It is slow (small images only).  Only tests/ may import it.
+"""
+import math
+import struct
+
+import numpy as np
+
+F32 = np.float32
+F64 = np.float64
+
+
+def cv_round(v):
+    """cvRound: round half to even (np.rint) on the value's own precision."""
+    return int(np.rint(v))
+
+
+# ----------------------------------------------------------------------------- model
+class Cascade:
+    pass
+
+
+def load_hcc(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"HCC1"
+    win_w, win_h, nst, ntr, nnd, nlf, flags = struct.unpack_from("<7i", b, 4)
+    p = 32
+    c = Cascade()
+    c.win_w, c.win_h, c.tilted = win_w, win_h, flags & 1
+    st = np.frombuffer(b, dtype=np.dtype([("thr", "<f8"), ("nt", "<i4"), ("par", "<i4"), ("nxt", "<i4")]), count=nst, offset=p)
+    p += nst * 20
+    c.stage_thr_raw = st["thr"].copy()
+    # A.2: (float)t - 1e-5f evaluated in f32
+    c.stage_thr = (st["thr"].astype(F32) - F32(1e-5)).astype(F32)
+    c.stage_ntrees = st["nt"].copy()
+    c.tree_nnodes = np.frombuffer(b, "<i4", ntr, p).copy()
+    p += ntr * 4
+    nd = np.frombuffer(b, dtype=np.dtype([("r", "i1", (3, 4)), ("w", "<f4", 3), ("thr", "<f4"), ("left", "<i4"),
+                                          ("right", "<i4"), ("tilted", "<i4")]), count=nnd, offset=p)
+    p += nnd * 40
+    c.rects = nd["r"].astype(np.int32)
+    c.weights = nd["w"].copy()
+    c.node_thr = nd["thr"].copy()
+    c.node_left = nd["left"].copy()
+    c.node_right = nd["right"].copy()
+    c.leaves = np.frombuffer(b, "<f4", nlf, p).copy()
+    c.max_nodes = int(c.tree_nnodes.max())
+    return c
+
+
+# ----------------------------------------------------------------------------- plan (A.3, A.6b)
+def plan(c, rows, cols, sf=1.1, min_size=(0, 0), max_size=(0, 0)):
+    min_w, min_h = min_size
+    max_w, max_h = max_size
+    if max_w == 0 or max_h == 0:
+        max_w, max_h = cols, rows
+    if rows < c.win_h or cols < c.win_w:
+        return [], 0
+    all_scales = []
+    factor = 1.0
+    while True:
+        ww, wh = cv_round(c.win_w * factor), cv_round(c.win_h * factor)
+        if ww > cols or wh > rows:
+            break
+        all_scales.append(F32(factor))
+        factor *= sf
+    scales = []
+    for s in all_scales:
+        ww, wh = cv_round(F32(c.win_w) * s), cv_round(F32(c.win_h) * s)
+        if ww > max_w or wh > max_h:
+            break
+        if ww < min_w or wh < min_h:
+            continue
+        scales.append(s)
+    if not scales and all_scales:
+        d = [(min_w - cv_round(F32(c.win_w) * s)) ** 2 + (min_h - cv_round(F32(c.win_h) * s)) ** 2 for s in all_scales]
+        scales.append(all_scales[int(np.argmin(d))])
+    levels = []
+    for sc in scales:
+        w = cv_round(F32(cols) / sc)
+        h = cv_round(F32(rows) / sc)
+        ystep = 1 if sc >= 2 else 2
+        levels.append(dict(scale=sc, w=w, h=h, ystep=ystep, szw_w=max(w + 1 - c.win_w, 0), szw_h=max(h + 1 - c.win_h, 0),
+                           win_w=cv_round(F32(c.win_w) * sc), win_h=cv_round(F32(c.win_h) * sc)))
+    if not levels:
+        return [], 0
+    nstripes = int(math.ceil(levels[0]["szw_w"] / 32.0))
+    for l in levels:
+        l["stripe"] = max((l["szw_h"] // l["ystep"] + nstripes - 1) // max(nstripes, 1), 1) * l["ystep"]
+        l["y_end"] = min(nstripes * l["stripe"], l["szw_h"])
+    return levels, nstripes
+
+
+# ----------------------------------------------------------------------------- resize (A.4)
+def lin_coeffs(src, dst):
+    """(ofs, c1) per destination index; replicate zones folded in as c1 = 0 with a clamped ofs.
+
+    fval = scale*(d+0.5)-0.5 with scale = 1/(dst/src) in f64.  The fraction is ALSO computed in
+    exact rational arithmetic ((2d+1)*src - dst)/(2*dst) and the test-suite asserts that both
+    roundings agree for the ladder sizes (they can differ only if the f64 product lands on the
+    other side of a .5/256 tie)."""
+    inv_scale = F64(dst) / F64(src)
+    scale = F64(1.0) / inv_scale
+    d = np.arange(dst, dtype=F64)
+    fval = scale * (d + 0.5) - 0.5
+    ival = np.floor(fval).astype(np.int64)
+    ofs = np.zeros(dst, np.int64)
+    c1 = np.zeros(dst, np.int64)
+    if src > 1:
+        main = (ival >= 0) & (ival < src - 1)
+        ofs[main] = ival[main]
+        c1[main] = np.rint((fval[main] - ival[main]) * 256.0).astype(np.int64)
+        right = ival >= src - 1
+        ofs[right] = src - 1
+    return ofs, c1
+
+
+def lin_coeffs_rational(src, dst):
+    """Exact-arithmetic version of the ideal coefficients (no f64 rounding of scale)."""
+    ofs, c1 = [], []
+    for d in range(dst):
+        num = (2 * d + 1) * src - dst          # fval = num / (2*dst)
+        den = 2 * dst
+        iv = num // den
+        if iv >= 0 and src > 1:
+            if iv < src - 1:
+                fr_num = (num - iv * den) * 256   # frac*256 = fr_num/den
+                q, r = divmod(fr_num, den)
+                if 2 * r > den or (2 * r == den and (q & 1)):
+                    q += 1
+                ofs.append(iv)
+                c1.append(q)
+            else:
+                ofs.append(src - 1)
+                c1.append(0)
+        else:
+            ofs.append(0)
+            c1.append(0)
+    return np.array(ofs, np.int64), np.array(c1, np.int64)
+
+
+def resize_linear_exact(img, drows, dcols):
+    rows, cols = img.shape
+    if (rows, cols) == (drows, dcols):
+        return img.copy()
+    ox, cx1 = lin_coeffs(cols, dcols)
+    oy, cy1 = lin_coeffs(rows, drows)
+    cx0, cy0 = 256 - cx1, 256 - cy1
+    s = img.astype(np.int64)
+    ox1 = np.minimum(ox + 1, cols - 1)
+    oy1 = np.minimum(oy + 1, rows - 1)
+    h = s[:, ox] * cx0[None, :] + s[:, ox1] * cx1[None, :]         # 8.8 fixed point, <= 65280
+    v = h[oy, :] * cy0[:, None] + h[oy1, :] * cy1[:, None]          # 16.16
+    return np.minimum((v + 32768) >> 16, 255).astype(np.uint8)
+
+
+# ----------------------------------------------------------------------------- integral (A.5)
+def integral(img):
+    rows, cols = img.shape
+    v = img.astype(np.uint64)
+    s = np.zeros((rows + 1, cols + 1), np.uint64)
+    q = np.zeros((rows + 1, cols + 1), np.uint64)
+    s[1:, 1:] = np.cumsum(np.cumsum(v, axis=0), axis=1)
+    q[1:, 1:] = np.cumsum(np.cumsum(v * v, axis=0), axis=1)
+    return (s & 0xFFFFFFFF).astype(np.uint32), (q & 0xFFFFFFFF).astype(np.uint32)   # modulo 2^32
+
+
+# ----------------------------------------------------------------------------- dense evaluation
+def _rect_sum(I, xs, ys, r):
+    x, y, w, h = (int(t) for t in r)
+    a = I[np.ix_(ys + y, xs + x)]
+    b = I[np.ix_(ys + y, xs + x + w)]
+    cc = I[np.ix_(ys + y + h, xs + x)]
+    d = I[np.ix_(ys + y + h, xs + x + w)]
+    return (a - b - cc + d).astype(np.uint32).view(np.int32)        # wraps like int32
+
+
+def _feature(c, S, xs, ys, ni, vnf):
+    w = c.weights[ni]
+    ret = w[0] * _rect_sum(S, xs, ys, c.rects[ni, 0]).astype(F32)
+    ret = (ret + w[1] * _rect_sum(S, xs, ys, c.rects[ni, 1]).astype(F32)).astype(F32)
+    if w[2] != 0:
+        ret = (ret + w[2] * _rect_sum(S, xs, ys, c.rects[ni, 2]).astype(F32)).astype(F32)
+    return (ret * vnf).astype(F32)
+
+
+def dense_stage_pass(c, S, Q, level):
+    """For every grid position of a level: -1 not evaluable, else number of stages passed
+    *if evaluated* (no skip logic here)."""
+    ys_ = np.arange(0, level["szw_h"], level["ystep"])
+    xs_ = np.arange(0, level["szw_w"], level["ystep"])
+    if len(ys_) == 0 or len(xs_) == 0:
+        return np.zeros((len(ys_), len(xs_)), np.int32)
+    nr = (1, 1, c.win_w - 2, c.win_h - 2)
+    valsum = _rect_sum(S, xs_, ys_, nr).astype(F64)
+    valsq = _rect_sum(Q, xs_, ys_, nr).view(np.uint32).astype(F64)
+    area = F64((c.win_w - 2) * (c.win_h - 2))
+    nf = area * valsq - valsum * valsum
+    pos = nf > 0
+    vnf = np.ones(nf.shape, F32)
+    vnf[pos] = (1.0 / np.sqrt(nf[pos])).astype(F32)
+    evaluable = pos & (area * vnf.astype(F64) < 1e-1)
+    nst = len(c.stage_thr)
+    passed = np.full(nf.shape, nst, np.int32)
+    alive = evaluable.copy()
+    node0 = 0
+    leaf0 = 0
+    tree = 0
+    for si in range(nst):
+        tmp = np.zeros(nf.shape, F64)
+        for _ in range(int(c.stage_ntrees[si])):
+            nn = int(c.tree_nnodes[tree])
+            if c.max_nodes == 1:
+                v = _feature(c, S, xs_, ys_, node0, vnf).astype(F64)
+                tmp += np.where(v < F64(c.node_thr[node0]), F64(c.leaves[leaf0]), F64(c.leaves[leaf0 + 1]))
+            else:
+                idx = np.zeros(nf.shape, np.int32)
+                leafv = np.zeros(nf.shape, F64)
+                done = np.zeros(nf.shape, bool)
+                for _depth in range(nn + 1):
+                    for k in range(nn):
+                        m = (~done) & (idx == k)
+                        if not m.any():
+                            continue
+                        v = _feature(c, S, xs_, ys_, node0 + k, vnf).astype(F64)
+                        nxt = np.where(v < F64(c.node_thr[node0 + k]), c.node_left[node0 + k], c.node_right[node0 + k])
+                        idx = np.where(m, nxt, idx)
+                        fin = m & (nxt <= 0)
+                        leafv = np.where(fin, c.leaves[leaf0 - np.minimum(nxt, 0)].astype(F64), leafv)
+                        done |= fin
+                    if done.all():
+                        break
+                tmp += leafv
+            node0 += nn
+            leaf0 += nn + 1
+            tree += 1
+        fail = alive & (tmp < F64(c.stage_thr[si]))
+        passed[fail] = si
+        alive &= ~fail
+    passed[~evaluable] = -1
+    return passed
+
+
+def apply_skip(passed, level):
+    """Closed form of A.7 on a dense 'passed' grid: returns taps with -2 for unvisited."""
+    ny_all, nx_all = passed.shape
+    taps = np.full(passed.shape, -2, np.int8)
+    ny = (level["y_end"] + level["ystep"] - 1) // level["ystep"]
+    for gy in range(min(ny, ny_all)):
+        f = passed[gy] == 0                      # evaluable and fails stage 0 if evaluated
+        # anchors: k == 0 or not f[k-1]; visited iff distance to nearest anchor at/left is even
+        anchor = np.ones(nx_all, bool)
+        anchor[1:] = ~f[:-1]
+        idx = np.arange(nx_all)
+        last_anchor = np.maximum.accumulate(np.where(anchor, idx, 0))
+        vis = ((idx - last_anchor) % 2) == 0
+        taps[gy, vis] = passed[gy, vis]
+    return taps
+
+
+# ----------------------------------------------------------------------------- grouping (A.10)
+def _similar(a, b, eps):
+    delta = eps * (min(a[2], b[2]) + min(a[3], b[3])) * 0.5
+    return (abs(a[0] - b[0]) <= delta and abs(a[1] - b[1]) <= delta and
+            abs(a[0] + a[2] - b[0] - b[2]) <= delta and abs(a[1] + a[3] - b[1] - b[3]) <= delta)
+
+
+def group_rectangles(rects, thr, eps=0.2):
+    rects = [tuple(int(v) for v in r) for r in rects]
+    if thr <= 0 or not rects:
+        return rects
+    n = len(rects)
+    # connected components by BFS (independent of the union-find in the C++ oracle)
+    label = [-1] * n
+    ncls = 0
+    for i in range(n):
+        if label[i] >= 0:
+            continue
+        label[i] = ncls
+        stack = [i]
+        while stack:
+            a = stack.pop()
+            for j in range(n):
+                if label[j] < 0 and _similar(rects[a], rects[j], eps):
+                    label[j] = ncls
+                    stack.append(j)
+        ncls += 1
+    sums = np.zeros((ncls, 4), np.int64)
+    cnt = np.zeros(ncls, np.int64)
+    for r, k in zip(rects, label):
+        sums[k] += r
+        cnt[k] += 1
+    mean = []
+    for k in range(ncls):
+        s = F32(1.0) / F32(cnt[k])
+        mean.append(tuple(cv_round(F32(v) * s) for v in sums[k]))
+    out = []
+    for i in range(ncls):
+        r1, n1 = mean[i], cnt[i]
+        if n1 <= thr:
+            continue
+        keep = True
+        for j in range(ncls):
+            n2 = cnt[j]
+            if j == i or n2 <= thr:
+                continue
+            r2 = mean[j]
+            dx, dy = cv_round(r2[2] * eps), cv_round(r2[3] * eps)
+            if (r1[0] >= r2[0] - dx and r1[1] >= r2[1] - dy and r1[0] + r1[2] <= r2[0] + r2[2] + dx and
+                    r1[1] + r1[3] <= r2[1] + r2[3] + dy and (n2 > max(3, n1) or n1 < 3)):
+                keep = False
+                break
+        if keep:
+            out.append(r1)
+    return out
+
+
+# ----------------------------------------------------------------------------- whole call
+def detect(c, gray, sf=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), want_taps=False):
+    rows, cols = gray.shape
+    levels, _ = plan(c, rows, cols, sf, min_size, max_size)
+    raw, taps_all = [], []
+    nst = len(c.stage_thr)
+    for l in levels:
+        img = resize_linear_exact(gray, l["h"], l["w"])
+        S, Q = integral(img)
+        passed = dense_stage_pass(c, S, Q, l)
+        taps = apply_skip(passed, l)
+        taps_all.append(taps)
+        gy, gx = np.nonzero(taps == nst)
+        for y, x in zip(gy, gx):          # row-major == scale -> y -> x
+            xx, yy = int(x) * l["ystep"], int(y) * l["ystep"]
+            raw.append((cv_round(F32(xx) * l["scale"]), cv_round(F32(yy) * l["scale"]), l["win_w"], l["win_h"]))
+    grouped = group_rectangles(raw, min_neighbors, 0.2)
+    if want_taps:
+        return grouped, raw, taps_all
+    return grouped, raw
