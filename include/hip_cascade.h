@@ -1,0 +1,154 @@
+/*
+ * hip_cascade.h -- C ABI of the MI355X-native Haar-cascade detection backend.
+ *
+ * Drop-in boundary.  The reference reaches the hot path through exactly
+ * two OpenCV member calls on one cv::CascadeClassifier object:
+ *
+ *   cascade_.load(cfg.detection.cascade_filepath.native())        reference src/file_io.cc:11
+ *   cascade.detectMultiScale(gray, facesInGray, cfg.scale, 2,
+ *                            0|CASCADE_SCALE_IMAGE, Size(30,30))   reference src/tracker/detector.cc:25-31
+ *
+ * Each entry point below names the reference interface it replaces.  The C++ shim
+ * ugproj-detector_amd/hip_cascade/cascade_classifier.hpp wraps this ABI behind the
+ * cv::CascadeClassifier spelling so the tracker's call-site is the only line that
+ * changes.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Never throws or aborts
+ * across the ABI: every function returns an hc_status (0 = OK, the reference's own
+ * convention at src/tracker/main.cc:14-41 and src/file_io.cc:7-15).
+ * There is NO CPU fallback: without a HIP device every compute entry point fails
+ * with HC_ERR_NO_DEVICE.
+ */
+#ifndef HIP_CASCADE_H
+#define HIP_CASCADE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HC_API __attribute__((visibility("default")))
+
+typedef enum hc_status {
+  HC_OK = 0,
+  HC_ERR_IO = -1,            /* file missing / unreadable                          */
+  HC_ERR_FORMAT = -2,        /* not an opencv-haar-classifier XML / HCC1 container */
+  HC_ERR_ARG = -3,           /* bad argument (scaleFactor <= 1, null pointer, ...)  */
+  HC_ERR_UNSUPPORTED = -4,   /* tilted features, malformed trees                   */
+  HC_ERR_NO_DEVICE = -5,     /* no HIP device / HIP runtime error at init          */
+  HC_ERR_HIP = -6,           /* HIP runtime error (hc_last_error() has the text)   */
+  HC_ERR_CAPACITY = -7,      /* caller's output buffer too small                   */
+  HC_ERR_CAND_OVERFLOW = -8, /* raw-candidate workspace overflow (raise cand_capacity) */
+  HC_ERR_STATE = -9          /* call order violated (e.g. wait without enqueue)    */
+} hc_status;
+
+/* cv::Rect layout: x, y, width, height (reference uses std::vector<cv::Rect>,
+ * src/tracker/detector.cc:24). */
+typedef struct hc_rect { int32_t x, y, width, height; } hc_rect;
+
+typedef struct hc_cascade hc_cascade;   /* immutable model; replaces cv::CascadeClassifier's loaded state */
+typedef struct hc_context hc_context;   /* device workspace + stream; single caller at a time          */
+
+/* ---- model: replaces cv::CascadeClassifier::load (reference src/file_io.cc:11) -------- */
+/* Accepts the old-format XML the reference ships (data/haarcascade_frontalface_*.xml,
+ * root type_id="opencv-haar-classifier") and the packed HCC1 container
+ * (tools/pack_cascade.py).  Pure host code, needs no device. */
+HC_API int  hc_cascade_load(const char* path, hc_cascade** out);
+HC_API void hc_cascade_free(hc_cascade* c);
+/* cv::CascadeClassifier::empty / getOriginalWindowSize analogues. */
+HC_API int  hc_cascade_info(const hc_cascade* c, int* win_w, int* win_h, int* nstages, int* is_tree);
+/* Flat model dump for loader-parity tests (same layout as oracle's orc_cascade_dump). */
+HC_API int  hc_cascade_counts(const hc_cascade* c, int* ntrees, int* nnodes, int* nleaves);
+HC_API int  hc_cascade_dump(const hc_cascade* c, float* stage_thr, int32_t* stage_ntrees,
+                            int32_t* tree_nnodes, int32_t* node_rects, float* node_thr,
+                            int32_t* node_left, int32_t* node_right, float* leaves);
+
+/* ---- the call: replaces cv::CascadeClassifier::detectMultiScale
+ *      (reference src/tracker/detector.cc:25-31) ------------------------------------------
+ * Synchronous, host image in, host rectangles out (the reference's calling convention:
+ * one frame at a time from one thread, src/tracker/face_tracker.cc:93-152).
+ * `flags` is accepted and ignored exactly as OpenCV >= 4 ignores it for this path.
+ * max_w/max_h == 0 means "image size" (cv::Size()).  `out` is overwritten.
+ * Uses an internal per-cascade context on the current HIP device. */
+HC_API int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes,
+                                double scale_factor, int min_neighbors, int flags,
+                                int min_w, int min_h, int max_w, int max_h,
+                                hc_rect* out, int out_capacity, int* out_count);
+
+/* ---- throughput path: batched, device-resident, asynchronous -------------------------- */
+/* stream: a hipStream_t to enqueue on, or NULL for a stream owned by the context. */
+HC_API int  hc_context_create(const hc_cascade* c, int device, void* stream, hc_context** out);
+HC_API void hc_context_destroy(hc_context* ctx);
+/* Fix geometry + call parameters and allocate the persistent workspace (no hipMalloc
+ * happens on the detect path afterwards).  cand_capacity = raw candidates per frame
+ * the workspace can hold (0 -> default 4096). */
+HC_API int  hc_context_configure(hc_context* ctx, int rows, int cols, double scale_factor,
+                                 int min_neighbors, int min_w, int min_h, int max_w, int max_h,
+                                 int max_batch, int cand_capacity);
+/* Enqueue detection of nframes 8-bit gray frames that already live in device memory
+ * (frame f at d_frames + f*frame_stride_bytes, rows row_step_bytes apart). Asynchronous. */
+HC_API int  hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes,
+                                    size_t row_step_bytes, int nframes);
+/* Same, from host memory (adds the H2D copy on the context stream). */
+HC_API int  hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_t frame_stride_bytes,
+                                         size_t row_step_bytes, int nframes);
+/* Wait for the enqueued batch, group rectangles, return them frame by frame:
+ * frame f's boxes are out[offsets[f] .. offsets[f+1]) ; offsets has nframes+1 entries. */
+HC_API int  hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets);
+/* Raw (ungrouped) candidates of the last waited batch, canonical order (scale,y,x) per frame. */
+HC_API int  hc_batch_raw_candidates(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets);
+
+/* ---- plan introspection (tests, bench accounting) -------------------------------------- */
+typedef struct hc_level {
+  float   scale;
+  int32_t w, h, ystep;
+  int32_t szw_w, szw_h;   /* valid origins x < szw_w, y < szw_h                     */
+  int32_t y_end;          /* rows actually scanned: y < y_end (stripe rule)         */
+  int32_t nx, ny;         /* scanned grid: ceil(szw_w/ystep) x ceil(y_end/ystep)    */
+  int32_t win_w, win_h;   /* emitted rectangle size                                 */
+  int32_t int_pitch;      /* integral row pitch in words                            */
+  int64_t pyr_ofs;        /* byte offset of the level in the per-frame pyramid      */
+  int64_t int_ofs;        /* word offset of the level in the per-frame integral     */
+  int64_t grid_ofs;       /* element offset of the level in per-frame grid arrays   */
+} hc_level;
+HC_API int hc_context_levels(const hc_context* ctx, hc_level* levels, int cap, int* nlevels);
+/* Same plan without a device (pure host): the scale ladder / level geometry that
+ * detectMultiScale would use for a rows x cols image.  *nlevels = 0 when the image is
+ * smaller than the window. */
+HC_API int hc_plan_query(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h,
+                         int max_w, int max_h, hc_level* levels, int cap, int* nlevels, int64_t* algorithmic_bytes);
+/* Host rectangle grouping used inside the call: cv::groupRectangles(rects, group_threshold, eps)
+ * semantics (GROUP_EPS = 0.2 in detectMultiScale).  In and out may alias. */
+HC_API int hc_group_rectangles(const hc_rect* in, int n, int group_threshold, double eps, hc_rect* out, int cap,
+                               int* nout);
+/* Algorithmic bytes per frame of the configured plan: W*H + sum 16*(w+1)*(h+1). */
+HC_API int64_t hc_context_algorithmic_bytes(const hc_context* ctx);
+
+/* ---- debug taps (tests only; copy device intermediates of the LAST batch to host) ------ */
+typedef enum hc_tap {
+  HC_TAP_PYRAMID = 0,   /* u8  [h][w] tight                                          */
+  HC_TAP_SUM = 1,       /* i32 [(h+1)][(w+1)] tight                                  */
+  HC_TAP_SQSUM = 2,     /* i32 [(h+1)][(w+1)] tight                                  */
+  HC_TAP_VNF = 3,       /* f32 [ny][nx], 0 = not evaluable                           */
+  HC_TAP_STAGES = 4     /* i8  [ceil(szw_h/ystep)][nx]: -2 unvisited, -1 not evaluable,
+                           k = stages passed (nstages = detection)                   */
+} hc_tap;
+/* Taps of kind HC_TAP_STAGES are only recorded when enabled before the enqueue. */
+HC_API int hc_context_enable_stage_taps(hc_context* ctx, int enable);
+HC_API int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* dst, size_t dst_bytes);
+
+/* ---- profiling: per-kernel device time of the last waited batch (HIP events) ----------- */
+#define HC_NKERNELS 5   /* resize, integral_rows, integral_cols, variance, cascade */
+HC_API int hc_context_enable_timing(hc_context* ctx, int enable);
+HC_API int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]);
+HC_API const char* hc_kernel_name(int i);
+
+HC_API const char* hc_last_error(void);
+HC_API const char* hc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit for bit,
+at every tap of the path -- pyramid bytes, integral words, variance factors, per-window
+stage-pass counts, raw candidates in canonical order, grouped boxes.
+
+Integer/byte/index work: exact equality.  The only floating-point tap (vnf, f32) is also
+compared for exact bit equality (tolerance 0): the path is defined by its IEEE operation order.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CALL = dict(scale_factor=1.1, min_neighbors=2, min_size=(30, 30))      # reference detector.cc:25-31
+
+
+def _oracle_taps_per_level(oc, frame, sf, min_size):
+    grouped, raw, taps = oc.detect(frame, sf, 2, min_size, (0, 0), want_taps=True)
+    return grouped, raw, taps
+
+
+def _check_frame_all_taps(pkg, oracle, ctx, oc, frame, fidx, sf, min_size):
+    levels = ctx.levels()
+    olevels, _ = oc.plan(frame.shape[0], frame.shape[1], sf, min_size)
+    assert len(levels) == len(olevels)
+    grouped, raw, otaps = _oracle_taps_per_level(oc, frame, sf, min_size)
+    for li, (L, OL) in enumerate(zip(levels, olevels)):
+        assert (L.w, L.h, L.ystep, L.nx, L.ny, L.win_w, L.win_h) == (OL.w, OL.h, OL.ystep, OL.nx, OL.ny, OL.win_w, OL.win_h)
+        assert np.float32(L.scale).tobytes() == np.float32(OL.scale).tobytes()
+        img = oracle.resize_linear_exact(frame, L.h, L.w)
+        pyr = ctx.read_tap(fidx, li, pkg.TAP_PYRAMID)
+        assert np.array_equal(pyr, img), "pyramid bytes differ at level %d" % li
+        s, q = oracle.integral(img)
+        assert np.array_equal(ctx.read_tap(fidx, li, pkg.TAP_SUM), s), "sum differs at level %d" % li
+        assert np.array_equal(ctx.read_tap(fidx, li, pkg.TAP_SQSUM), q), "sqsum differs at level %d" % li
+        st = ctx.read_tap(fidx, li, pkg.TAP_STAGES)
+        assert st.shape == otaps[li].shape
+        assert np.array_equal(st, otaps[li]), "stage-pass counts differ at level %d: %d positions" % (
+            li, int((st != otaps[li]).sum()))
+    return grouped, raw
+
+
+@pytest.mark.parametrize("name", ["alt", "alt2", "default", "alt_tree"])
+def test_all_taps_small_planted(pkg, oracle, synth, name):
+    """Every intermediate of the path on a 240x320 planted frame, all four reference cascades."""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(i), nfaces=3, min_size=40, max_size=110)[0]
+                       for i in range(2)])
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=2, cand_capacity=1 << 14)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    raws = ctx.raw_candidates(2)
+    for f in range(2):
+        grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[f], f, 1.1, (30, 30))
+        assert np.array_equal(raws[f], raw), "raw candidates (canonical order) differ"
+        assert np.array_equal(got[f], grouped), "grouped boxes differ (order included)"
+    assert sum(len(g) for g in got) > 0
+
+
+def test_vnf_bits(pkg, oracle, synth):
+    """A.6a: f64 sqrt / divide / f32 rounding on the device must be correctly rounded: compare the
+    variance tap against a numpy f64 recomputation from the oracle's integrals, bit for bit."""
+    path = oracle.cascade_path("alt")
+    casc = pkg.Cascade(path)
+    frame = synth.texture(200, 260, synth.frame_seed(5))
+    ctx = pkg.Context(casc)
+    ctx.configure(200, 260, 1.1, 2, (0, 0), (0, 0), max_batch=1)
+    ctx.detect_host(frame[None])
+    for li, L in enumerate(ctx.levels()):
+        img = oracle.resize_linear_exact(frame, L.h, L.w)
+        s, q = oracle.integral(img)
+        s = s.astype(np.int64)
+        q = q.view(np.uint32).astype(np.int64)
+        ys = np.arange(L.ny) * L.ystep + 1
+        xs = np.arange(L.nx) * L.ystep + 1
+        nw, nh = casc.win_w - 2, casc.win_h - 2
+
+        def rs(I, mod):
+            v = I[np.ix_(ys, xs)] - I[np.ix_(ys, xs + nw)] - I[np.ix_(ys + nh, xs)] + I[np.ix_(ys + nh, xs + nw)]
+            return v % mod if mod else v
+        valsum = rs(s, 0).astype(np.float64)
+        valsq = rs(q, 1 << 32).astype(np.float64)
+        area = float(nw * nh)
+        nf = area * valsq - valsum * valsum
+        want = np.zeros(nf.shape, np.float32)
+        pos = nf > 0
+        v = (1.0 / np.sqrt(nf[pos])).astype(np.float32)
+        v[~(area * v.astype(np.float64) < 1e-1)] = 0
+        want[pos] = v
+        got = ctx.read_tap(0, li, pkg.TAP_VNF)
+        assert got.tobytes() == want.tobytes(), "vnf bits differ at level %d" % li
+
+
+def test_sync_call_matches_oracle_with_row_step(pkg, oracle, synth):
+    """hc_detect_multiscale (the literal detectMultiScale replacement) on a non-contiguous view."""
+    path = oracle.cascade_path("alt")
+    big, _ = synth.planted(300, 420, synth.frame_seed(3), nfaces=3, min_size=40, max_size=120)
+    view = big[10:290, 7:407]                       # step_bytes (420) != cols (400)
+    got = pkg.Cascade(path).detect_multiscale(view, **CALL)
+    want, _ = oracle.OracleCascade(path).detect(np.ascontiguousarray(view), 1.1, 2, (30, 30))
+    assert np.array_equal(got, want)
+    assert len(want) > 0
+
+
+@pytest.mark.parametrize("shape", [(19, 40), (20, 20), (21, 23), (33, 31), (64, 47), (97, 131)])
+def test_edge_sizes(pkg, oracle, synth, shape):
+    """Smaller than the window (no levels), exactly the window, ragged sizes; minSize unset."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frame = synth.texture(shape[0], shape[1], synth.frame_seed(shape[0] * 1000 + shape[1]))
+    got = casc.detect_multiscale(frame, 1.1, 0, 0, (0, 0))      # minNeighbors 0: raw candidates come back
+    want, raw = oc.detect(frame, 1.1, 0, (0, 0))
+    assert np.array_equal(got, want)
+    if shape[0] >= 20 and shape[1] >= 20:
+        ctx = pkg.Context(casc)
+        ctx.configure(shape[0], shape[1], 1.1, 0, (0, 0), (0, 0), 1)
+        ctx.enable_stage_taps(True)
+        ctx.detect_host(frame[None])
+        _check_frame_all_taps(pkg, oracle, ctx, oc, frame, 0, 1.1, (0, 0))
+
+
+def test_constant_and_masked_frames(pkg, oracle, synth):
+    """Constant image: every window has nf == 0 -> nothing evaluable, no detections.  Half-masked
+    frame (the reference zeroes non-skin pixels, detector.cc:22): flat regions next to texture."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    const = np.full((120, 160), 77, np.uint8)
+    assert len(casc.detect_multiscale(const, 1.1, 0, 0, (0, 0))) == 0
+    fr, _ = synth.planted(240, 320, synth.frame_seed(9), nfaces=3, min_size=40, max_size=110)
+    fr = fr.copy()
+    fr[:, :130] = 0
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), 1)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(fr[None])
+    grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
+    assert np.array_equal(got[0], grouped)
+
+
+def test_noise_skip_chain(pkg, oracle, synth):
+    """iid noise fails stage 0 almost everywhere -> long x-skip chains across tile boundaries."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr = synth.noise(150, 700, synth.frame_seed(11))
+    ctx = pkg.Context(casc)
+    ctx.configure(150, 700, 1.1, 2, (0, 0), (0, 0), 1)
+    ctx.enable_stage_taps(True)
+    ctx.detect_host(fr[None])
+    _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (0, 0))
+
+
+def test_scale_factor_and_size_limits(pkg, oracle, synth):
+    path = oracle.cascade_path("alt2")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr, _ = synth.planted(240, 320, synth.frame_seed(21), nfaces=4, min_size=40, max_size=110)
+    for sf, mn, mins, maxs in [(1.2, 3, (0, 0), (0, 0)), (1.05, 2, (40, 40), (90, 90)), (1.3, 1, (24, 24), (0, 0)),
+                               (1.1, 2, (200, 200), (200, 200))]:
+        got = casc.detect_multiscale(fr, sf, mn, 0, mins, maxs)
+        want, _ = oc.detect(fr, sf, mn, mins, maxs)
+        assert np.array_equal(got, want), (sf, mn, mins, maxs)
+
+
+def test_batch_determinism_and_device_input(pkg, oracle, synth):
+    """Same frames through batch slots / repeated runs give identical bytes (stands in for a race
+    detector on the device), and the device-resident entry point equals the host one."""
+    path = oracle.cascade_path("alt")
+    casc = pkg.Cascade(path)
+    frames = np.stack([synth.planted(180, 240, synth.frame_seed(i), nfaces=2, min_size=40, max_size=80)[0]
+                       for i in range(5)])
+    ctx = pkg.Context(casc)
+    ctx.configure(180, 240, 1.1, 2, (30, 30), (0, 0), max_batch=8, cand_capacity=1 << 14)
+    a = ctx.detect_host(frames)
+    b = ctx.detect_host(frames[::-1].copy())[::-1]
+    c = ctx.detect_host(frames)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    single = [casc.detect_multiscale(f, **CALL) for f in frames]
+    for x, y in zip(a, single):
+        assert np.array_equal(x, y)
+
+
+def test_full_size_720p_alt(pkg, oracle, synth):
+    """BASELINE config #2 at full size: 1280x720, alt, sf 1.1, minNeighbors 2, minSize 30.
+    Boxes + raw candidates + per-window stage counts against the oracle on one planted frame and
+    one noise frame (oracle ~1 s per frame)."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted(720, 1280, synth.frame_seed(0))[0], synth.noise(720, 1280, synth.frame_seed(1))])
+    ctx = pkg.Context(casc)
+    ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=2, cand_capacity=1 << 14)
+    assert ctx.algorithmic_bytes() == 33813536                    # SURVEY 8d / BASELINE.md section 4
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    raws = ctx.raw_candidates(2)
+    assert len(ctx.levels()) == 33
+    for f in range(2):
+        grouped, raw, otaps = oc.detect(frames[f], 1.1, 2, (30, 30), (0, 0), want_taps=True)
+        for li in range(33):
+            assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (f, li)
+        assert np.array_equal(raws[f], raw)
+        assert np.array_equal(got[f], grouped)
+    assert len(got[0]) >= 5

@@ -1,0 +1,247 @@
+"""ctypes binding of libhip_cascade.so (C ABI: include/hip_cascade.h).
+
+Host-side mirror, for tests and bench.py, of the two calls the reference makes on its
+cv::CascadeClassifier (reference src/file_io.cc:11 `load`, src/tracker/detector.cc:25-31
+`detectMultiScale`).  The reference is C++, so the *product* host layer is the C++ shim
+in hip_cascade/cascade_classifier.hpp; this module only exposes the same C ABI to Python.
+
+There is no fallback of any kind: if the shared library is missing, import fails loudly;
+if no HIP device is present, every compute call raises HipCascadeError(HC_ERR_NO_DEVICE).
+
+The directory name contains a hyphen, so load this package with `load_package()` from
+tests/conftest.py / bench.py (importlib by path) under the module name `ugproj_detector_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhip_cascade.so")
+
+HC_NKERNELS = 5
+TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES = range(5)
+
+STATUS = {0: "HC_OK", -1: "HC_ERR_IO", -2: "HC_ERR_FORMAT", -3: "HC_ERR_ARG", -4: "HC_ERR_UNSUPPORTED",
+          -5: "HC_ERR_NO_DEVICE", -6: "HC_ERR_HIP", -7: "HC_ERR_CAPACITY", -8: "HC_ERR_CAND_OVERFLOW",
+          -9: "HC_ERR_STATE"}
+
+
+class HipCascadeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class Level(C.Structure):
+    _fields_ = [("scale", C.c_float), ("w", C.c_int32), ("h", C.c_int32), ("ystep", C.c_int32),
+                ("szw_w", C.c_int32), ("szw_h", C.c_int32), ("y_end", C.c_int32), ("nx", C.c_int32),
+                ("ny", C.c_int32), ("win_w", C.c_int32), ("win_h", C.c_int32), ("int_pitch", C.c_int32),
+                ("pyr_ofs", C.c_int64), ("int_ofs", C.c_int64), ("grid_ofs", C.c_int64)]
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("libhip_cascade.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "or `make -C ugproj-detector_amd` -- there is no fallback implementation" % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+# every symbol declared in include/hip_cascade.h (tests/test_abi.py checks the header against this list)
+_SIGS = {
+    "hc_cascade_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "hc_cascade_free": (None, [C.c_void_p]),
+    "hc_cascade_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
+    "hc_cascade_counts": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 3),
+    "hc_cascade_dump": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
+    "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.POINTER(C.c_int)]),
+    "hc_context_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hc_context_destroy": (None, [C.c_void_p]),
+    "hc_context_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
+    "hc_detect_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+    "hc_detect_batch_enqueue_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+    "hc_detect_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hc_batch_raw_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hc_context_levels": (C.c_int, [C.c_void_p, C.POINTER(Level), C.c_int, C.POINTER(C.c_int)]),
+    "hc_context_algorithmic_bytes": (C.c_int64, [C.c_void_p]),
+    "hc_plan_query": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 4 +
+                      [C.POINTER(Level), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "hc_group_rectangles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                      C.POINTER(C.c_int)]),
+    "hc_context_enable_stage_taps": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_context_read_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "hc_context_enable_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_context_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "hc_kernel_name": (C.c_char_p, [C.c_int]),
+    "hc_last_error": (C.c_char_p, []),
+    "hc_version": (C.c_char_p, []),
+}
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)      # AttributeError here == the ABI lost a symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+EXPORTED = sorted(_SIGS)
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipCascadeError(rc, lib.hc_last_error().decode())
+
+
+class Cascade:
+    """cv::CascadeClassifier stand-in: load() + detectMultiScale()."""
+
+    def __init__(self, path):
+        self._h = C.c_void_p()
+        _check(lib.hc_cascade_load(os.fsencode(path), C.byref(self._h)))
+        v = [C.c_int() for _ in range(4)]
+        _check(lib.hc_cascade_info(self._h, *[C.byref(x) for x in v]))
+        self.win_w, self.win_h, self.nstages, self.is_tree = [x.value for x in v]
+        v = [C.c_int() for _ in range(3)]
+        _check(lib.hc_cascade_counts(self._h, *[C.byref(x) for x in v]))
+        self.ntrees, self.nnodes, self.nleaves = [x.value for x in v]
+
+    def close(self):
+        if self._h:
+            lib.hc_cascade_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def dump(self):
+        st = np.zeros(self.nstages, np.float32)
+        sn = np.zeros(self.nstages, np.int32)
+        tn = np.zeros(self.ntrees, np.int32)
+        nr = np.zeros(self.nnodes * 15, np.int32)
+        nt = np.zeros(self.nnodes, np.float32)
+        nl = np.zeros(self.nnodes, np.int32)
+        nrr = np.zeros(self.nnodes, np.int32)
+        lf = np.zeros(self.nleaves, np.float32)
+        _check(lib.hc_cascade_dump(self._h, *[a.ctypes.data for a in (st, sn, tn, nr, nt, nl, nrr, lf)]))
+        return st, sn, tn, nr, nt, nl, nrr, lf
+
+    def plan(self, rows, cols, scale_factor=1.1, min_size=(0, 0), max_size=(0, 0)):
+        """(levels, algorithmic_bytes) of the call on a rows x cols image; pure host."""
+        buf = (Level * 256)()
+        n = C.c_int()
+        ab = C.c_int64()
+        _check(lib.hc_plan_query(self._h, rows, cols, scale_factor, min_size[0], min_size[1], max_size[0],
+                                 max_size[1], buf, 256, C.byref(n), C.byref(ab)))
+        return [buf[i] for i in range(n.value)], ab.value
+
+    def detect_multiscale(self, gray, scale_factor=1.1, min_neighbors=3, flags=0, min_size=(0, 0), max_size=(0, 0),
+                          capacity=4096):
+        """detectMultiScale(image, scaleFactor, minNeighbors, flags, minSize, maxSize) -> (K,4) int32 x,y,w,h."""
+        gray = np.asarray(gray)
+        if gray.dtype != np.uint8 or gray.ndim != 2 or gray.strides[1] != 1:
+            raise ValueError("need a 2-D uint8 image with unit column stride")
+        out = np.zeros((capacity, 4), np.int32)
+        n = C.c_int()
+        _check(lib.hc_detect_multiscale(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                        scale_factor, min_neighbors, flags, min_size[0], min_size[1], max_size[0],
+                                        max_size[1], out.ctypes.data, capacity, C.byref(n)))
+        return out[:n.value].copy()
+
+
+class Context:
+    """Batched, device-resident detection context (one stream, one workspace)."""
+
+    def __init__(self, cascade, device=0, stream=None):
+        self.cascade = cascade
+        self._h = C.c_void_p()
+        _check(lib.hc_context_create(cascade._h, device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.max_batch = 0
+
+    def close(self):
+        if self._h:
+            lib.hc_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, rows, cols, scale_factor=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), max_batch=1,
+                  cand_capacity=0):
+        _check(lib.hc_context_configure(self._h, rows, cols, scale_factor, min_neighbors, min_size[0], min_size[1],
+                                        max_size[0], max_size[1], max_batch, cand_capacity))
+        self.rows, self.cols, self.max_batch = rows, cols, max_batch
+
+    def levels(self):
+        buf = (Level * 256)()
+        n = C.c_int()
+        _check(lib.hc_context_levels(self._h, buf, 256, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def algorithmic_bytes(self):
+        return int(lib.hc_context_algorithmic_bytes(self._h))
+
+    def enqueue_device(self, dptr, nframes, frame_stride=None, row_step=None):
+        _check(lib.hc_detect_batch_enqueue(self._h, C.c_void_p(dptr), frame_stride or self.rows * self.cols,
+                                           row_step or self.cols, nframes))
+
+    def enqueue_host(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.ndim == 3 and frames.shape[1:] == (self.rows, self.cols)
+        self._keep = frames
+        _check(lib.hc_detect_batch_enqueue_host(self._h, frames.ctypes.data, frames.strides[0], frames.strides[1],
+                                                frames.shape[0]))
+        self._n = frames.shape[0]
+
+    def wait(self, nframes=None, capacity=1 << 16):
+        nframes = nframes if nframes is not None else self._n
+        out = np.zeros((capacity, 4), np.int32)
+        ofs = np.zeros(nframes + 1, np.int32)
+        _check(lib.hc_detect_batch_wait(self._h, out.ctypes.data, capacity, ofs.ctypes.data))
+        return [out[ofs[i]:ofs[i + 1]].copy() for i in range(nframes)]
+
+    def raw_candidates(self, nframes, capacity=1 << 20):
+        out = np.zeros((capacity, 4), np.int32)
+        ofs = np.zeros(nframes + 1, np.int32)
+        _check(lib.hc_batch_raw_candidates(self._h, out.ctypes.data, capacity, ofs.ctypes.data))
+        return [out[ofs[i]:ofs[i + 1]].copy() for i in range(nframes)]
+
+    def detect_host(self, frames):
+        self.enqueue_host(frames)
+        return self.wait(len(frames))
+
+    def enable_stage_taps(self, on=True):
+        _check(lib.hc_context_enable_stage_taps(self._h, int(on)))
+
+    def enable_timing(self, on=True):
+        _check(lib.hc_context_enable_timing(self._h, int(on)))
+
+    def kernel_ms(self):
+        ms = (C.c_float * HC_NKERNELS)()
+        _check(lib.hc_context_kernel_ms(self._h, ms))
+        return {lib.hc_kernel_name(i).decode(): float(ms[i]) for i in range(HC_NKERNELS)}
+
+    def read_tap(self, frame, level_index, what):
+        L = self.levels()[level_index]
+        if what == TAP_PYRAMID:
+            a = np.zeros((L.h, L.w), np.uint8)
+        elif what in (TAP_SUM, TAP_SQSUM):
+            a = np.zeros((L.h + 1, L.w + 1), np.int32)
+        elif what == TAP_VNF:
+            a = np.zeros((L.ny, L.nx), np.float32)
+        else:
+            a = np.zeros(((L.szw_h + L.ystep - 1) // L.ystep, L.nx), np.int8)
+        if a.size:
+            _check(lib.hc_context_read_tap(self._h, frame, level_index, what, a.ctypes.data, a.nbytes))
+        return a
+
+
+def group_rectangles(rects, group_threshold, eps=0.2):
+    rects = np.ascontiguousarray(np.asarray(rects, np.int32).reshape(-1, 4))
+    out = np.zeros((max(len(rects), 1), 4), np.int32)
+    n = C.c_int()
+    _check(lib.hc_group_rectangles(rects.ctypes.data, len(rects), group_threshold, eps, out.ctypes.data, len(out),
+                                   C.byref(n)))
+    return out[:n.value].copy()

@@ -1,0 +1,51 @@
+// device_types.h -- plain structs shared by host planning code and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace hc {
+
+// Cascade-kernel tiling: one workgroup (4 wavefronts of 64) owns BAND_ROWS grid rows of a
+// pyramid level and walks them left to right in steps of TILE_POS grid positions.
+constexpr int BAND_ROWS = 8;
+constexpr int TILE_POS = 64;
+constexpr int WG_THREADS = 256;
+
+struct DevLevel {
+  float scale;             // f32 scale factor of the level
+  int32_t w, h;            // level image size
+  int32_t ystep;           // 1 or 2
+  int32_t szw_w, szw_h;    // valid window origins: x < szw_w, y < szw_h
+  int32_t y_end;           // scanned rows: y < y_end
+  int32_t nx, ny, ny_all;  // grid: nx = ceil(szw_w/ystep), ny = ceil(y_end/ystep), ny_all = ceil(szw_h/ystep)
+  int32_t win_w, win_h;    // size of emitted rectangles
+  int32_t int_pitch;       // integral row pitch (words)
+  int32_t xtab_ofs, ytab_ofs;
+  int64_t pyr_ofs;         // bytes, inside one frame's pyramid
+  int64_t int_ofs;         // words, inside one frame's integral array
+  int64_t grid_ofs;        // elements, inside one frame's grid arrays (vnf, taps): [ny_all][nx]
+};
+
+struct WorkItem { int32_t level, a, b; };
+
+// LDS tile geometry of the cascade kernel for one ystep.
+struct TileGeom {
+  int32_t pitch;   // words per tile row
+  int32_t half;    // ystep 2: word offset of the odd-column plane inside a row (0 for ystep 1)
+  int32_t rows;    // integral rows staged
+  int32_t cols;    // integral columns staged
+};
+
+// One weak-classifier node, offsets pre-resolved for a TileGeom.
+struct DevNode {
+  uint16_t off[12];   // LDS word offsets of 3 rects x 4 corners relative to the window origin word
+  float w[3];         // raw rect weights (w[2] == 0 -> two-rect feature)
+  float thr;
+  uint32_t a, b;      // stump: f32 bits of left/right leaf; tree: int32 child codes (<=0 leaf, >0 node)
+};
+static_assert(sizeof(DevNode) == 48, "DevNode layout");
+
+struct DevStage { int32_t first, count; float thr; int32_t pad; };   // first/count in nodes (stump) or trees (tree)
+struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };
+
+}  // namespace hc

@@ -1,0 +1,613 @@
+// hc_api.cpp -- C ABI of the MI355X Haar-cascade backend (include/hip_cascade.h).
+//
+// Replaces, behind a plain-C boundary, the two OpenCV calls the reference makes on its
+// cv::CascadeClassifier: load (src/file_io.cc:11) and detectMultiScale
+// (src/tracker/detector.cc:25-31).  No CPU fallback exists in this library: every compute
+// entry point needs a HIP device and reports HC_ERR_NO_DEVICE / HC_ERR_HIP otherwise.
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hip_cascade.h"
+#include "cascade_model.h"
+#include "group_rects.h"
+#include "kernels.h"
+#include "scale_plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int set_err(int code, const std::string& what) { g_err = what; return code; }
+
+#define HIPCHK(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (expr);                                                                 \
+    if (e__ != hipSuccess)                                                                   \
+      return set_err(HC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+const char* const kKernelNames[HC_NKERNELS] = {"k_resize", "k_integral_rows", "k_integral_cols", "k_variance",
+                                               "k_cascade"};
+
+template <class T>
+int dev_alloc(T** p, size_t n) {
+  *p = nullptr;
+  if (n == 0) n = 1;
+  hipError_t e = hipMalloc((void**)p, n * sizeof(T));
+  if (e != hipSuccess) return set_err(HC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  return HC_OK;
+}
+
+template <class T>
+int dev_upload(T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return HC_OK;
+}
+
+}  // namespace
+
+struct hc_cascade {
+  hc::Model model;
+  std::mutex mu;                 // guards default_ctx (sync API)
+  hc_context* default_ctx = nullptr;
+};
+
+struct hc_context {
+  const hc_cascade* casc = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  hc::Plan plan;
+  bool configured = false;
+  int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
+  hc::TileGeom g1{}, g2{};
+  size_t lds_bytes = 0;
+
+  // device
+  uint8_t* d_frames = nullptr;   // staging for the host-input path
+  uint8_t* d_pyr = nullptr;
+  uint32_t* d_sum = nullptr;
+  uint32_t* d_sq = nullptr;
+  float* d_vnf = nullptr;
+  int8_t* d_taps = nullptr;
+  hc::DevLevel* d_levels = nullptr;
+  uint32_t* d_xtab = nullptr;
+  uint32_t* d_ytab = nullptr;
+  hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
+               *d_band_items = nullptr;
+  hc::DevNode *d_nodes1 = nullptr, *d_nodes2 = nullptr;
+  hc::DevStage* d_stages = nullptr;
+  hc::DevTree* d_trees = nullptr;
+  float* d_leaves = nullptr;
+  unsigned long long* d_cand = nullptr;
+  unsigned int* d_count = nullptr;
+  // pinned host
+  unsigned long long* h_cand = nullptr;
+  unsigned int* h_count = nullptr;
+
+  int pending = 0;               // frames enqueued and not yet waited
+  int last_frames = 0;
+  bool taps_enabled = false, timing_enabled = false, timed_last = false;
+  hipEvent_t ev[HC_NKERNELS + 1] = {};
+  float last_ms[HC_NKERNELS] = {};
+  std::vector<hc_rect> last_raw;
+  std::vector<int32_t> last_raw_ofs;
+
+  void free_workspace() {
+    void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
+                    d_row_items, d_col_items, d_var_items, d_band_items, d_cand, d_count};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    d_frames = d_pyr = nullptr; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
+    d_xtab = d_ytab = nullptr;
+    d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items = nullptr;
+    d_cand = nullptr; d_count = nullptr;
+    if (h_cand) (void)hipHostFree(h_cand);
+    if (h_count) (void)hipHostFree(h_count);
+    h_cand = nullptr; h_count = nullptr;
+    configured = false;
+  }
+};
+
+namespace {
+
+// LDS tile geometry + per-geometry corner offsets of every node
+hc::TileGeom make_geom(const hc::Model& m, int ystep) {
+  hc::TileGeom g{};
+  g.cols = (hc::TILE_POS - 1) * ystep + m.win_w + 1;
+  g.rows = (hc::BAND_ROWS - 1) * ystep + m.win_h + 1;
+  if (ystep == 1) { g.half = 0; g.pitch = g.cols; }
+  else { g.half = (g.cols + 1) / 2; g.pitch = 2 * g.half; }
+  return g;
+}
+
+void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vector<hc::DevNode>& out) {
+  out.clear();
+  out.reserve(m.nodes.size());
+  auto word = [&](int dx, int dy) {
+    const int col = ystep == 1 ? dx : ((dx & 1) * g.half + (dx >> 1));
+    return (uint16_t)(dy * g.pitch + col);
+  };
+  for (const hc::ModelTree& t : m.trees) {
+    for (int k = 0; k < t.nnodes; k++) {
+      const hc::ModelNode& n = m.nodes[t.first_node + k];
+      hc::DevNode d{};
+      for (int r = 0; r < 3; r++) {
+        const int x = n.rect[r][0], y = n.rect[r][1], w = n.rect[r][2], h = n.rect[r][3];
+        d.off[4 * r + 0] = word(x, y);
+        d.off[4 * r + 1] = word(x + w, y);
+        d.off[4 * r + 2] = word(x, y + h);
+        d.off[4 * r + 3] = word(x + w, y + h);
+        d.w[r] = n.weight[r];
+      }
+      d.thr = n.thr;
+      if (m.is_stump()) {
+        const float l = m.leaves[t.first_leaf + 0], r = m.leaves[t.first_leaf + 1];
+        memcpy(&d.a, &l, 4);
+        memcpy(&d.b, &r, 4);
+      } else {
+        d.a = (uint32_t)n.left;
+        d.b = (uint32_t)n.right;
+      }
+      out.push_back(d);
+    }
+  }
+}
+
+int upload_model(hc_context* c) {
+  const hc::Model& m = c->casc->model;
+  c->g1 = make_geom(m, 1);
+  c->g2 = make_geom(m, 2);
+  const size_t words = std::max((size_t)c->g1.pitch * c->g1.rows, (size_t)c->g2.pitch * c->g2.rows);
+  if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
+  c->lds_bytes = words * sizeof(int32_t);
+  std::vector<hc::DevNode> n1, n2;
+  build_nodes(m, c->g1, 1, n1);
+  build_nodes(m, c->g2, 2, n2);
+  std::vector<hc::DevStage> st;
+  std::vector<hc::DevTree> tr;
+  for (const hc::ModelStage& s : m.stages) {
+    hc::DevStage d{};
+    d.first = m.is_stump() ? m.trees[s.first_tree].first_node : s.first_tree;
+    d.count = s.ntrees;
+    d.thr = s.thr;
+    st.push_back(d);
+  }
+  for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
+  int rc;
+  if ((rc = dev_upload(&c->d_nodes1, n1))) return rc;
+  if ((rc = dev_upload(&c->d_nodes2, n2))) return rc;
+  if ((rc = dev_upload(&c->d_stages, st))) return rc;
+  if ((rc = dev_upload(&c->d_trees, tr))) return rc;
+  if ((rc = dev_upload(&c->d_leaves, m.leaves))) return rc;
+  return HC_OK;
+}
+
+hc_level to_public(const hc::DevLevel& L) {
+  hc_level o{};
+  o.scale = L.scale; o.w = L.w; o.h = L.h; o.ystep = L.ystep; o.szw_w = L.szw_w; o.szw_h = L.szw_h;
+  o.y_end = L.y_end; o.nx = L.nx; o.ny = L.ny; o.win_w = L.win_w; o.win_h = L.win_h; o.int_pitch = L.int_pitch;
+  o.pyr_ofs = L.pyr_ofs; o.int_ofs = L.int_ofs; o.grid_ofs = L.grid_ofs;
+  return o;
+}
+
+int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, size_t row_step, int nframes) {
+  const hc::Plan& P = c->plan;
+  const hc::Model& m = c->casc->model;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), s));
+  const bool timed = c->timing_enabled;
+  c->timed_last = timed;
+  if (!P.levels.empty()) {
+    const size_t pyr_stride = (size_t)P.pyr_bytes, int_stride = (size_t)P.int_words, grid_stride = (size_t)P.grid_elems;
+    if (c->taps_enabled) HIPCHK(hipMemsetAsync(c->d_taps, 0xFE, grid_stride * nframes, s));
+    int e;
+    if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
+    if ((e = hc::launch_resize(s, nframes, (int)P.resize_items.size(), d_frames, frame_stride, row_step, P.rows,
+                               P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_resize_items, c->d_pyr, pyr_stride)))
+      return set_err(HC_ERR_HIP, std::string("k_resize launch: ") + hipGetErrorString((hipError_t)e));
+    if (timed) HIPCHK(hipEventRecord(c->ev[1], s));
+    if ((e = hc::launch_integral_rows(s, nframes, (int)P.row_items.size(), c->d_pyr, pyr_stride, c->d_levels,
+                                      c->d_row_items, c->d_sum, c->d_sq, int_stride)))
+      return set_err(HC_ERR_HIP, std::string("k_integral_rows launch: ") + hipGetErrorString((hipError_t)e));
+    if (timed) HIPCHK(hipEventRecord(c->ev[2], s));
+    if ((e = hc::launch_integral_cols(s, nframes, (int)P.col_items.size(), c->d_levels, c->d_col_items, c->d_sum,
+                                      c->d_sq, int_stride)))
+      return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
+    if (timed) HIPCHK(hipEventRecord(c->ev[3], s));
+    if ((e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
+                                 int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
+      return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
+    if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
+    hc::CascadeArgs A{};
+    A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
+    A.levels = c->d_levels; A.bands = c->d_band_items; A.nbands = (int)P.band_items.size();
+    A.nodes1 = c->d_nodes1; A.nodes2 = c->d_nodes2; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
+    A.trees = c->d_trees; A.leaves = c->d_leaves; A.g1 = c->g1; A.g2 = c->g2;
+    A.cand = c->d_cand; A.cand_count = c->d_count;
+    A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
+    A.taps = c->taps_enabled ? c->d_taps : nullptr;
+    if ((e = hc::launch_cascade(s, nframes, !m.is_stump(), c->lds_bytes, A)))
+      return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
+    if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
+  }
+  HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  c->pending = nframes;
+  return HC_OK;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* hc_last_error(void) { return g_err.c_str(); }
+const char* hc_version(void) { return "hip_cascade 0.1 (gfx950)"; }
+const char* hc_kernel_name(int i) { return (i >= 0 && i < HC_NKERNELS) ? kKernelNames[i] : ""; }
+
+int hc_cascade_load(const char* path, hc_cascade** out) {
+  if (!path || !out) return set_err(HC_ERR_ARG, "null argument");
+  *out = nullptr;
+  hc_cascade* c = new hc_cascade;
+  std::string err;
+  int rc = hc::load_model(path, c->model, err);
+  if (rc != HC_OK) { delete c; return set_err(rc, err); }
+  *out = c;
+  return HC_OK;
+}
+
+void hc_cascade_free(hc_cascade* c) {
+  if (!c) return;
+  if (c->default_ctx) hc_context_destroy(c->default_ctx);
+  delete c;
+}
+
+int hc_cascade_info(const hc_cascade* c, int* win_w, int* win_h, int* nstages, int* is_tree) {
+  if (!c) return set_err(HC_ERR_ARG, "null cascade");
+  if (win_w) *win_w = c->model.win_w;
+  if (win_h) *win_h = c->model.win_h;
+  if (nstages) *nstages = (int)c->model.stages.size();
+  if (is_tree) *is_tree = c->model.is_stump() ? 0 : 1;
+  return HC_OK;
+}
+
+int hc_cascade_counts(const hc_cascade* c, int* ntrees, int* nnodes, int* nleaves) {
+  if (!c) return set_err(HC_ERR_ARG, "null cascade");
+  if (ntrees) *ntrees = (int)c->model.trees.size();
+  if (nnodes) *nnodes = (int)c->model.nodes.size();
+  if (nleaves) *nleaves = (int)c->model.leaves.size();
+  return HC_OK;
+}
+
+int hc_cascade_dump(const hc_cascade* c, float* stage_thr, int32_t* stage_ntrees, int32_t* tree_nnodes,
+                    int32_t* node_rects, float* node_thr, int32_t* node_left, int32_t* node_right, float* leaves) {
+  if (!c) return set_err(HC_ERR_ARG, "null cascade");
+  const hc::Model& m = c->model;
+  for (size_t i = 0; i < m.stages.size(); i++) {
+    if (stage_thr) stage_thr[i] = m.stages[i].thr;
+    if (stage_ntrees) stage_ntrees[i] = m.stages[i].ntrees;
+  }
+  if (tree_nnodes) for (size_t i = 0; i < m.trees.size(); i++) tree_nnodes[i] = m.trees[i].nnodes;
+  for (size_t i = 0; i < m.nodes.size(); i++) {
+    const hc::ModelNode& n = m.nodes[i];
+    if (node_rects)
+      for (int r = 0; r < 3; r++) {
+        for (int j = 0; j < 4; j++) node_rects[i * 15 + r * 5 + j] = n.rect[r][j];
+        node_rects[i * 15 + r * 5 + 4] = (int)n.weight[r];
+      }
+    if (node_thr) node_thr[i] = n.thr;
+    if (node_left) node_left[i] = n.left;
+    if (node_right) node_right[i] = n.right;
+  }
+  if (leaves) memcpy(leaves, m.leaves.data(), m.leaves.size() * sizeof(float));
+  return HC_OK;
+}
+
+int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context** out) {
+  if (!c || !out) return set_err(HC_ERR_ARG, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+  if (device < 0 || device >= ndev) return set_err(HC_ERR_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  hc_context* ctx = new hc_context;
+  ctx->casc = c;
+  ctx->device = device;
+  if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
+  else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return set_err(HC_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    ctx->own_stream = true;
+  }
+  for (auto& e : ctx->ev) {
+    if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
+  }
+  int rc = upload_model(ctx);
+  if (rc != HC_OK) { hc_context_destroy(ctx); return rc; }
+  *out = ctx;
+  return HC_OK;
+}
+
+void hc_context_destroy(hc_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  ctx->free_workspace();
+  void* ptrs[] = {ctx->d_nodes1, ctx->d_nodes2, ctx->d_stages, ctx->d_trees, ctx->d_leaves};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_factor, int min_neighbors, int min_w,
+                         int min_h, int max_w, int max_h, int max_batch, int cand_capacity) {
+  if (!ctx) return set_err(HC_ERR_ARG, "null context");
+  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");   // CV_Assert upstream
+  if (rows <= 0 || cols <= 0 || max_batch <= 0 || max_batch > 65535) return set_err(HC_ERR_ARG, "bad geometry / batch");
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->free_workspace();
+  hc::Plan& P = ctx->plan;
+  int rc = hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, P);
+  if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
+  for (const hc::DevLevel& L : P.levels)
+    if (L.nx > 65535 || L.ny_all > 65535 || P.levels.size() > 255) return set_err(HC_ERR_UNSUPPORTED, "frame too large");
+  ctx->max_batch = max_batch;
+  ctx->min_neighbors = min_neighbors;
+  ctx->cand_per_frame = cand_capacity > 0 ? cand_capacity : 4096;
+  const size_t B = (size_t)max_batch;
+  if ((rc = dev_alloc(&ctx->d_frames, B * rows * cols))) return rc;
+  if ((rc = dev_alloc(&ctx->d_pyr, B * P.pyr_bytes))) return rc;
+  if ((rc = dev_alloc(&ctx->d_sum, B * P.int_words))) return rc;
+  if ((rc = dev_alloc(&ctx->d_sq, B * P.int_words))) return rc;
+  if ((rc = dev_alloc(&ctx->d_vnf, B * P.grid_elems))) return rc;
+  if ((rc = dev_alloc(&ctx->d_taps, B * P.grid_elems))) return rc;
+  if ((rc = dev_alloc(&ctx->d_cand, B * ctx->cand_per_frame))) return rc;
+  if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
+  // row 0 / column 0 of every integral stay zero for the lifetime of the workspace
+  HIPCHK(hipMemset(ctx->d_sum, 0, std::max<size_t>(B * P.int_words, 1) * 4));
+  HIPCHK(hipMemset(ctx->d_sq, 0, std::max<size_t>(B * P.int_words, 1) * 4));
+  HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
+  if ((rc = dev_upload(&ctx->d_levels, P.levels))) return rc;
+  if ((rc = dev_upload(&ctx->d_xtab, P.xtab))) return rc;
+  if ((rc = dev_upload(&ctx->d_ytab, P.ytab))) return rc;
+  if ((rc = dev_upload(&ctx->d_resize_items, P.resize_items))) return rc;
+  if ((rc = dev_upload(&ctx->d_row_items, P.row_items))) return rc;
+  if ((rc = dev_upload(&ctx->d_col_items, P.col_items))) return rc;
+  if ((rc = dev_upload(&ctx->d_var_items, P.var_items))) return rc;
+  if ((rc = dev_upload(&ctx->d_band_items, P.band_items))) return rc;
+  HIPCHK(hipHostMalloc((void**)&ctx->h_cand, B * ctx->cand_per_frame * sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
+  ctx->pending = 0;
+  ctx->last_frames = 0;
+  ctx->configured = true;
+  return HC_OK;
+}
+
+int hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes, size_t row_step_bytes,
+                            int nframes) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!d_frames || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad frame pointer / batch size");
+  if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
+  HIPCHK(hipSetDevice(ctx->device));
+  return enqueue_device(ctx, d_frames, frame_stride_bytes, row_step_bytes, nframes);
+}
+
+int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_t frame_stride_bytes,
+                                 size_t row_step_bytes, int nframes) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!h_frames || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad frame pointer / batch size");
+  if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
+  for (int f = 0; f < nframes; f++)
+    HIPCHK(hipMemcpy2DAsync(ctx->d_frames + (size_t)f * rows * cols, cols, h_frames + (size_t)f * frame_stride_bytes,
+                            row_step_bytes, cols, rows, hipMemcpyHostToDevice, ctx->stream));
+  return enqueue_device(ctx, ctx->d_frames, rows * cols, cols, nframes);
+}
+
+int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!ctx->pending) return set_err(HC_ERR_STATE, "no batch enqueued");
+  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nframes = ctx->pending;
+  ctx->pending = 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->timed_last && !ctx->plan.levels.empty())
+    for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  const unsigned int count = *ctx->h_count;
+  const size_t cap = (size_t)ctx->cand_per_frame * ctx->max_batch;
+  ctx->last_frames = nframes;
+  ctx->last_raw.clear();
+  ctx->last_raw_ofs.assign(nframes + 1, 0);
+  if (count > cap) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; raise cand_capacity");
+  if (count) {
+    HIPCHK(hipMemcpyAsync(ctx->h_cand, ctx->d_cand, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  // canonical single-thread order: frame -> scale -> y -> x  == ascending key
+  std::sort(ctx->h_cand, ctx->h_cand + count);
+  const hc::Plan& P = ctx->plan;
+  ctx->last_raw.reserve(count);
+  size_t i = 0;
+  int total = 0;
+  std::vector<hc_rect> grp;
+  for (int f = 0; f < nframes; f++) {
+    grp.clear();
+    for (; i < count && (int)(ctx->h_cand[i] >> 40) == f; i++) {
+      const unsigned long long k = ctx->h_cand[i];
+      const hc::DevLevel& L = P.levels[(k >> 32) & 0xFF];
+      const int gy = (int)((k >> 16) & 0xFFFF), gx = (int)(k & 0xFFFF);
+      // Rect(cvRound(x*scale), cvRound(y*scale), winSize): int -> f32 times f32 scale
+      const hc_rect r{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale),
+                      (int)std::nearbyintf((float)(gy * L.ystep) * L.scale), L.win_w, L.win_h};
+      grp.push_back(r);
+    }
+    ctx->last_raw.insert(ctx->last_raw.end(), grp.begin(), grp.end());
+    ctx->last_raw_ofs[f + 1] = (int32_t)ctx->last_raw.size();
+    hc::group_rectangles(grp, ctx->min_neighbors, 0.2);     // GROUP_EPS upstream
+    offsets[f] = total;
+    if (total + (int)grp.size() > out_capacity) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
+    for (const hc_rect& r : grp) out[total++] = r;
+  }
+  offsets[nframes] = total;
+  return HC_OK;
+}
+
+int hc_batch_raw_candidates(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
+  if (!ctx || !offsets) return set_err(HC_ERR_ARG, "null argument");
+  if ((int)ctx->last_raw.size() > out_capacity) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
+  for (size_t i = 0; i < ctx->last_raw.size(); i++) out[i] = ctx->last_raw[i];
+  for (size_t i = 0; i < ctx->last_raw_ofs.size(); i++) offsets[i] = ctx->last_raw_ofs[i];
+  return HC_OK;
+}
+
+int hc_context_levels(const hc_context* ctx, hc_level* levels, int cap, int* nlevels) {
+  if (!ctx || !ctx->configured || !nlevels) return set_err(HC_ERR_STATE, "context not configured");
+  const auto& Ls = ctx->plan.levels;
+  *nlevels = (int)Ls.size();
+  if ((int)Ls.size() > cap) return set_err(HC_ERR_CAPACITY, "level buffer too small");
+  for (size_t i = 0; i < Ls.size(); i++) levels[i] = to_public(Ls[i]);
+  return HC_OK;
+}
+
+int hc_plan_query(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w,
+                  int max_h, hc_level* levels, int cap, int* nlevels, int64_t* algorithmic_bytes) {
+  if (!c || !nlevels) return set_err(HC_ERR_ARG, "null argument");
+  hc::Plan P;
+  int rc = hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, P);
+  if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
+  *nlevels = (int)P.levels.size();
+  if (algorithmic_bytes) *algorithmic_bytes = P.algorithmic_bytes;
+  if ((int)P.levels.size() > cap) return set_err(HC_ERR_CAPACITY, "level buffer too small");
+  for (size_t i = 0; i < P.levels.size(); i++) levels[i] = to_public(P.levels[i]);
+  return HC_OK;
+}
+
+int hc_group_rectangles(const hc_rect* in, int n, int group_threshold, double eps, hc_rect* out, int cap, int* nout) {
+  if ((!in && n > 0) || !nout || n < 0) return set_err(HC_ERR_ARG, "null argument");
+  std::vector<hc_rect> v(in, in + n);
+  hc::group_rectangles(v, group_threshold, eps);
+  if ((int)v.size() > cap) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
+  for (size_t i = 0; i < v.size(); i++) out[i] = v[i];
+  *nout = (int)v.size();
+  return HC_OK;
+}
+
+int64_t hc_context_algorithmic_bytes(const hc_context* ctx) {
+  return (ctx && ctx->configured) ? ctx->plan.algorithmic_bytes : 0;
+}
+
+int hc_context_enable_stage_taps(hc_context* ctx, int enable) {
+  if (!ctx) return set_err(HC_ERR_ARG, "null context");
+  ctx->taps_enabled = enable != 0;
+  return HC_OK;
+}
+
+int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* dst, size_t dst_bytes) {
+  if (!ctx || !ctx->configured || !dst) return set_err(HC_ERR_STATE, "context not configured");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "batch still in flight");
+  if (frame < 0 || frame >= ctx->last_frames || level < 0 || level >= (int)ctx->plan.levels.size())
+    return set_err(HC_ERR_ARG, "frame / level out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  const hc::Plan& P = ctx->plan;
+  const hc::DevLevel& L = P.levels[level];
+  switch (what) {
+    case HC_TAP_PYRAMID: {
+      const size_t n = (size_t)L.w * L.h;
+      if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      HIPCHK(hipMemcpy(dst, ctx->d_pyr + (size_t)frame * P.pyr_bytes + L.pyr_ofs, n, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    case HC_TAP_SUM:
+    case HC_TAP_SQSUM: {
+      const size_t wbytes = (size_t)(L.w + 1) * 4;
+      if (dst_bytes < wbytes * (L.h + 1)) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      const uint32_t* src = (what == HC_TAP_SUM ? ctx->d_sum : ctx->d_sq) + (size_t)frame * P.int_words + L.int_ofs;
+      HIPCHK(hipMemcpy2D(dst, wbytes, src, (size_t)L.int_pitch * 4, wbytes, L.h + 1, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    case HC_TAP_VNF: {
+      const size_t n = (size_t)L.nx * L.ny * 4;
+      if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      if (n) HIPCHK(hipMemcpy(dst, ctx->d_vnf + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    case HC_TAP_STAGES: {
+      if (!ctx->taps_enabled) return set_err(HC_ERR_STATE, "stage taps were not enabled");
+      const size_t n = (size_t)L.nx * L.ny_all;
+      if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      if (n) HIPCHK(hipMemcpy(dst, ctx->d_taps + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    default:
+      return set_err(HC_ERR_ARG, "unknown tap");
+  }
+}
+
+int hc_context_enable_timing(hc_context* ctx, int enable) {
+  if (!ctx) return set_err(HC_ERR_ARG, "null context");
+  ctx->timing_enabled = enable != 0;
+  return HC_OK;
+}
+
+int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]) {
+  if (!ctx || !ms) return set_err(HC_ERR_ARG, "null argument");
+  if (!ctx->timed_last) return set_err(HC_ERR_STATE, "timing was not enabled for the last batch");
+  for (int i = 0; i < HC_NKERNELS; i++) ms[i] = ctx->last_ms[i];
+  return HC_OK;
+}
+
+// ---- synchronous single-frame call: the literal replacement of
+//      cascade.detectMultiScale(gray, faces, scale, 2, 0|CASCADE_SCALE_IMAGE, Size(30,30))
+int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,
+                         int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h, hc_rect* out,
+                         int out_capacity, int* out_count) {
+  (void)flags;   // ignored by the OpenCV >= 4 evaluation path for this cascade format
+  if (!c || !gray || !out_count) return set_err(HC_ERR_ARG, "null argument");
+  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
+  *out_count = 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  int dev = 0;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+  HIPCHK(hipGetDevice(&dev));
+  hc_context* ctx = c->default_ctx;
+  if (ctx && ctx->device != dev) { hc_context_destroy(ctx); ctx = c->default_ctx = nullptr; }
+  int rc;
+  if (!ctx) {
+    if ((rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
+    c->default_ctx = ctx;
+  }
+  const hc::Plan& P = ctx->plan;
+  const int emw = (max_w == 0 || max_h == 0) ? cols : max_w, emh = (max_w == 0 || max_h == 0) ? rows : max_h;
+  if (!ctx->configured || P.rows != rows || P.cols != cols || P.scale_factor != scale_factor || P.min_w != min_w ||
+      P.min_h != min_h || P.max_w != emw || P.max_h != emh || ctx->min_neighbors != min_neighbors) {
+    if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, 1, 1 << 16)))
+      return rc;
+  }
+  if ((rc = hc_detect_batch_enqueue_host(ctx, gray, 0, step_bytes, 1))) return rc;
+  int32_t ofs[2] = {0, 0};
+  if ((rc = hc_detect_batch_wait(ctx, out, out_capacity, ofs))) return rc;
+  *out_count = ofs[1];
+  return HC_OK;
+}
+
+}  // extern "C"

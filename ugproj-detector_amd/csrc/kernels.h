@@ -1,0 +1,48 @@
+// kernels.h -- launch interface of kernels.hip (host side sees only plain pointers).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "device_types.h"
+
+namespace hc {
+
+struct CascadeArgs {
+  const uint32_t* sum;        // per-frame integral arrays, frame stride int_stride words
+  size_t int_stride;
+  const float* vnf;           // per-frame grid arrays, frame stride grid_stride elements
+  size_t grid_stride;
+  const DevLevel* levels;
+  const WorkItem* bands;
+  int nbands;
+  const DevNode* nodes1;      // offsets resolved for g1 (ystep 1)
+  const DevNode* nodes2;      // offsets resolved for g2 (ystep 2)
+  const DevStage* stages;
+  int nstages;
+  const DevTree* trees;
+  const float* leaves;
+  TileGeom g1, g2;
+  unsigned long long* cand;   // raw candidate keys: frame<<40 | level<<32 | gy<<16 | gx
+  unsigned int* cand_count;
+  unsigned int cand_cap;
+  int8_t* taps;               // nullable: per-position stage-pass counts
+};
+
+// all launchers return 0 or a hipError_t value
+int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames, size_t frame_stride,
+                  size_t row_step, int rows, int cols, const DevLevel* levels, const uint32_t* xtab,
+                  const uint32_t* ytab, const WorkItem* items, uint8_t* pyr, size_t pyr_stride);
+int launch_integral_rows(hipStream_t st, int nframes, int nitems, const uint8_t* pyr, size_t pyr_stride,
+                         const DevLevel* levels, const WorkItem* items, uint32_t* sum, uint32_t* sq,
+                         size_t int_stride);
+int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
+                         uint32_t* sum, uint32_t* sq, size_t int_stride);
+int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
+                    const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
+                    float* vnf, size_t grid_stride);
+int launch_cascade(hipStream_t st, int nframes, bool tree, size_t lds_bytes, const CascadeArgs& args);
+
+}  // namespace hc

@@ -1,0 +1,137 @@
+// scale_plan.cpp -- host planning for one detectMultiScale configuration.
+//
+// Follows OpenCV >= 4 CascadeClassifierImpl::detectMultiScaleNoGrouping +
+// FeatureEvaluator::updateScaleData as restated in SURVEY.md A.3/A.6b for the call at
+// reference src/tracker/detector.cc:25-31 (scaleFactor = cfg.detection.scale, default 1.1
+// at reference src/structure.cc:83-85; minSize 30x30; maxSize unset).
+
+#include "scale_plan.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/hip_cascade.h"
+
+namespace hc {
+
+namespace {
+// round-half-to-even, the behaviour of cvRound on x86-64
+inline int rne(double v) { return (int)std::nearbyint(v); }
+inline int rne(float v) { return (int)std::nearbyintf(v); }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+void build_resize_table(int src, int dst, std::vector<uint32_t>& out) {
+  // cv::resize(INTER_LINEAR_EXACT) coefficient rule: all in IEEE f64,
+  // coefficient as 8-bit fixed point, border zones folded in as c1 = 0.
+  const double inv_scale = (double)dst / (double)src;
+  const double scale = 1.0 / inv_scale;
+  out.reserve(out.size() + dst);
+  for (int d = 0; d < dst; d++) {
+    const double center = scale * ((double)d + 0.5) - 0.5;
+    const double fl = std::floor(center);
+    uint32_t ofs = 0, c1 = 0;
+    if (fl >= 0.0 && src > 1) {
+      if (fl < (double)(src - 1)) {
+        ofs = (uint32_t)fl;
+        c1 = (uint32_t)rne((center - fl) * 256.0);
+      } else {
+        ofs = (uint32_t)(src - 1);   // right/bottom replicate zone
+      }
+    }                                // else: left/top replicate zone -> ofs 0, c1 0
+    out.push_back((ofs << 9) | c1);
+  }
+}
+
+int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
+               int max_w, int max_h, Plan& p) {
+  p = Plan{};
+  p.rows = rows; p.cols = cols; p.scale_factor = scale_factor;
+  p.min_w = min_w; p.min_h = min_h;
+  if (!(scale_factor > 1.0) || rows <= 0 || cols <= 0) return HC_ERR_ARG;
+  if (max_w == 0 || max_h == 0) { max_w = cols; max_h = rows; }
+  p.max_w = max_w; p.max_h = max_h;
+  p.algorithmic_bytes = (int64_t)rows * cols;
+  if (rows < m.win_h || cols < m.win_w) return HC_OK;
+
+  // ---- scale ladder: every factor whose window fits the image, then the min/max filter
+  std::vector<float> fits;
+  {
+    double factor = 1.0;
+    while (rne(m.win_w * factor) <= cols && rne(m.win_h * factor) <= rows) {
+      fits.push_back((float)factor);
+      factor *= scale_factor;
+    }
+  }
+  std::vector<float> ladder;
+  for (float s : fits) {
+    const int ww = rne((float)m.win_w * s), wh = rne((float)m.win_h * s);
+    if (ww > max_w || wh > max_h) break;
+    if (ww >= min_w && wh >= min_h) ladder.push_back(s);
+  }
+  if (ladder.empty() && !fits.empty()) {
+    // nearest precomputed scale (minSize == maxSize single-scale use)
+    size_t best = 0;
+    double best_d = 0;
+    for (size_t i = 0; i < fits.size(); i++) {
+      const double dw = min_w - rne((float)m.win_w * fits[i]), dh = min_h - rne((float)m.win_h * fits[i]);
+      const double d = dw * dw + dh * dh;
+      if (i == 0 || d < best_d) { best = i; best_d = d; }
+    }
+    ladder.push_back(fits[best]);
+  }
+  if (ladder.empty()) return HC_OK;
+
+  // ---- level geometry + workspace layout
+  for (float sc : ladder) {
+    DevLevel L{};
+    L.scale = sc;
+    L.w = rne((float)cols / sc);
+    L.h = rne((float)rows / sc);
+    L.ystep = sc >= 2.f ? 1 : 2;
+    L.szw_w = std::max(L.w + 1 - m.win_w, 0);
+    L.szw_h = std::max(L.h + 1 - m.win_h, 0);
+    L.win_w = rne((float)m.win_w * sc);
+    L.win_h = rne((float)m.win_h * sc);
+    L.int_pitch = (int)align_up(L.w + 1, 16);
+    L.pyr_ofs = p.pyr_bytes;
+    L.int_ofs = p.int_words;
+    L.xtab_ofs = (int)p.xtab.size();
+    L.ytab_ofs = (int)p.ytab.size();
+    build_resize_table(cols, L.w, p.xtab);
+    build_resize_table(rows, L.h, p.ytab);
+    p.pyr_bytes += align_up((int64_t)L.w * L.h, 64);
+    p.int_words += (int64_t)L.int_pitch * (L.h + 1);
+    p.algorithmic_bytes += 16ll * (L.w + 1) * (L.h + 1);
+    p.levels.push_back(L);
+  }
+  // stripe rule: the scanned rows are the union of nstripes stripes whose size is
+  // derived with truncating divisions -> trailing rows can drop out
+  p.nstripes = (int)std::ceil(p.levels[0].szw_w / 32.0);
+  for (DevLevel& L : p.levels) {
+    const int per = std::max(ceil_div(L.szw_h / L.ystep, std::max(p.nstripes, 1)), 1) * L.ystep;
+    L.y_end = std::min(p.nstripes * per, L.szw_h);
+    L.nx = ceil_div(L.szw_w, L.ystep);
+    L.ny = ceil_div(L.y_end, L.ystep);
+    L.ny_all = ceil_div(L.szw_h, L.ystep);
+    L.grid_ofs = p.grid_elems;
+    p.grid_elems += align_up((int64_t)L.nx * L.ny_all, 64);
+  }
+
+  // ---- launch work lists (largest levels first == ladder order)
+  for (int li = 0; li < (int)p.levels.size(); li++) {
+    const DevLevel& L = p.levels[li];
+    for (int y0 = 0; y0 < L.h; y0 += 4)
+      for (int x0 = 0; x0 < L.w; x0 += 64) p.resize_items.push_back(WorkItem{li, x0, y0});
+    for (int y0 = 0; y0 < L.h; y0 += 4) p.row_items.push_back(WorkItem{li, y0, 0});
+    for (int x0 = 0; x0 < L.w; x0 += WG_THREADS) p.col_items.push_back(WorkItem{li, x0, 0});
+    const int npos = L.nx * L.ny;
+    for (int i0 = 0; i0 < npos; i0 += WG_THREADS) p.var_items.push_back(WorkItem{li, i0, 0});
+    if (L.nx > 0)
+      for (int gy0 = 0; gy0 < L.ny; gy0 += BAND_ROWS) p.band_items.push_back(WorkItem{li, gy0, 0});
+  }
+  return HC_OK;
+}
+
+}  // namespace hc
