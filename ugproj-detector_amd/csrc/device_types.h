@@ -45,7 +45,9 @@ struct DevNode {
 };
 static_assert(sizeof(DevNode) == 48, "DevNode layout");
 
-struct DevStage { int32_t first, count; float thr; int32_t pad; };   // first/count in nodes (stump) or trees (tree)
+// first/count in nodes (stump) or trees (tree); exact != 0: the f64 sum of any subset of the
+// stage's leaf values is exact in any order (sparse stump-parallel mode is then bit-identical)
+struct DevStage { int32_t first, count; float thr; int32_t exact; };
 struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };
 
 }  // namespace hc

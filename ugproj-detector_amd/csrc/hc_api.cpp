@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -73,6 +74,8 @@ struct hc_context {
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
   hc::TileGeom g1{}, g2{};
   size_t lds_bytes = 0;
+  int tile_words = 0;
+  int sparse_max = 32;
 
   // device
   uint8_t* d_frames = nullptr;   // staging for the host-input path
@@ -164,13 +167,41 @@ void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vect
   }
 }
 
+// True when every partial sum of the stage's leaf values, in any order, is exactly
+// representable in f64: all leaves are integer multiples of q = 2^emin and sum |leaf| / q < 2^53.
+// The sequential f64 accumulation of upstream then equals the mathematical sum,
+// and so does any re-association of it.
+bool stage_sum_is_exact(const hc::Model& m, const hc::ModelStage& s) {
+  int emin = INT32_MAX;
+  const int t0 = s.first_tree, t1 = s.first_tree + s.ntrees;
+  const int l0 = m.trees[t0].first_leaf, l1 = m.trees[t1 - 1].first_leaf + m.trees[t1 - 1].nnodes + 1;
+  for (int i = l0; i < l1; i++) {
+    const float v = m.leaves[i];
+    if (v == 0.f) continue;
+    if (!std::isfinite(v)) return false;
+    int e;
+    std::frexp(v, &e);              // |v| = f * 2^e, f in [0.5, 1): the f32 ulp is 2^(e-24)
+    emin = std::min(emin, e - 24);
+  }
+  if (emin == INT32_MAX) return true;
+  long double units = 0;            // 64-bit mantissa: exact for these magnitudes
+  for (int i = l0; i < l1; i++) {
+    const long double u = std::ldexp((long double)std::fabs(m.leaves[i]), -emin);
+    if (u > 0x1p60L) return false;
+    units += u;
+  }
+  return units < 0x1p53L;
+}
+
 int upload_model(hc_context* c) {
   const hc::Model& m = c->casc->model;
   c->g1 = make_geom(m, 1);
   c->g2 = make_geom(m, 2);
   const size_t words = std::max((size_t)c->g1.pitch * c->g1.rows, (size_t)c->g2.pitch * c->g2.rows);
   if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
-  c->lds_bytes = words * sizeof(int32_t);
+  c->tile_words = (int)words;
+  // tile | vnf[512] f32 | 2 queues x 512 u16 | 4 counters   (k_cascade LDS layout)
+  c->lds_bytes = words * 4 + (size_t)hc::BAND_ROWS * hc::TILE_POS * (4 + 2 * 2) + 16;
   std::vector<hc::DevNode> n1, n2;
   build_nodes(m, c->g1, 1, n1);
   build_nodes(m, c->g2, 2, n2);
@@ -181,6 +212,7 @@ int upload_model(hc_context* c) {
     d.first = m.is_stump() ? m.trees[s.first_tree].first_node : s.first_tree;
     d.count = s.ntrees;
     d.thr = s.thr;
+    d.exact = stage_sum_is_exact(m, s) ? 1 : 0;
     st.push_back(d);
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
@@ -233,7 +265,9 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
     A.levels = c->d_levels; A.bands = c->d_band_items; A.nbands = (int)P.band_items.size();
     A.nodes1 = c->d_nodes1; A.nodes2 = c->d_nodes2; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
-    A.trees = c->d_trees; A.leaves = c->d_leaves; A.g1 = c->g1; A.g2 = c->g2;
+    if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) A.nstages = std::min(A.nstages, std::max(1, atoi(e_)));   // timing experiments only
+    A.trees = c->d_trees; A.leaves = c->d_leaves; A.g1 = c->g1; A.g2 = c->g2; A.tile_words = c->tile_words;
+    A.sparse_max = c->sparse_max;
     A.cand = c->d_cand; A.cand_count = c->d_count;
     A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
     A.taps = c->taps_enabled ? c->d_taps : nullptr;
@@ -333,6 +367,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   for (auto& e : ctx->ev) {
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
+  if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knob
   int rc = upload_model(ctx);
   if (rc != HC_OK) { hc_context_destroy(ctx); return rc; }
   *out = ctx;
@@ -430,7 +465,8 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (ctx->timed_last && !ctx->plan.levels.empty())
     for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
-  const unsigned int count = *ctx->h_count;
+  unsigned int count = *ctx->h_count;
+  if (getenv("HC_DEBUG_MAX_STAGES") && count > (size_t)ctx->cand_per_frame * ctx->max_batch) count = 0;   // timing experiments only
   const size_t cap = (size_t)ctx->cand_per_frame * ctx->max_batch;
   ctx->last_frames = nframes;
   ctx->last_raw.clear();

@@ -25,6 +25,8 @@ struct CascadeArgs {
   const DevTree* trees;
   const float* leaves;
   TileGeom g1, g2;
+  int sparse_max;             // stages with <= sparse_max survivors in a tile run in sparse mode
+  int tile_words;             // LDS words reserved for the integral tile (max over g1, g2)
   unsigned long long* cand;   // raw candidate keys: frame<<40 | level<<32 | gy<<16 | gx
   unsigned int* cand_count;
   unsigned int cand_cap;

@@ -169,13 +169,33 @@ __global__ __launch_bounds__(WG_THREADS) void k_variance(
 //
 // Rect corner offsets are pre-resolved on the host into LDS word offsets (DevNode::off) and
 // are wave-uniform -> scalar loads; a lane's corner address is base + off.
-__device__ __forceinline__ float feature_value(const int32_t* tile, int base, const HC_CONST DevNode& n, float vnf) {
-  const int s0 = tile[base + n.off[0]] - tile[base + n.off[1]] - tile[base + n.off[2]] + tile[base + n.off[3]];
-  const int s1 = tile[base + n.off[4]] - tile[base + n.off[5]] - tile[base + n.off[6]] + tile[base + n.off[7]];
-  float ret = n.w[0] * (float)s0 + n.w[1] * (float)s1;
-  if (n.w[2] != 0.0f) {   // wave-uniform branch
-    const int s2 = tile[base + n.off[8]] - tile[base + n.off[9]] - tile[base + n.off[10]] + tile[base + n.off[11]];
-    ret += n.w[2] * (float)s2;
+// A node is fetched as three 16-byte scalar loads into SGPRs (values, never addresses: the
+// compiler must not turn the leaf select into a per-lane memory load) and the next node is
+// requested before the current one is evaluated, so the scalar-load latency hides behind the
+// LDS reads and the arithmetic of the current node.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct NodeRegs { u32x4 q0, q1, q2; };   // q0,q1: off[0..7] + off[8..11] | w0 w1 ; q2: w2 thr a b
+
+__device__ __forceinline__ NodeRegs load_node(const HC_CONST DevNode* nodes, int idx) {
+  const HC_CONST u32x4* p = (const HC_CONST u32x4*)(nodes + idx);
+  NodeRegs r;
+  r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2];
+  return r;
+}
+
+#define HC_OFF(q, k) (int)(((q)[(k) >> 1] >> (((k)&1) * 16)) & 0xffffu)
+
+__device__ __forceinline__ float feature_value(const int32_t* tile, int base, const NodeRegs& n, float vnf) {
+  const int s0 = tile[base + HC_OFF(n.q0, 0)] - tile[base + HC_OFF(n.q0, 1)] - tile[base + HC_OFF(n.q0, 2)] +
+                 tile[base + HC_OFF(n.q0, 3)];
+  const int s1 = tile[base + HC_OFF(n.q0, 4)] - tile[base + HC_OFF(n.q0, 5)] - tile[base + HC_OFF(n.q0, 6)] +
+                 tile[base + HC_OFF(n.q0, 7)];
+  const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]), w2 = __uint_as_float(n.q2[0]);
+  float ret = w0 * (float)s0 + w1 * (float)s1;
+  if (w2 != 0.0f) {   // wave-uniform branch
+    const int s2 = tile[base + HC_OFF(n.q1, 0)] - tile[base + HC_OFF(n.q1, 1)] - tile[base + HC_OFF(n.q1, 2)] +
+                   tile[base + HC_OFF(n.q1, 3)];
+    ret += w2 * (float)s2;
   }
   return ret * vnf;
 }
@@ -185,31 +205,95 @@ __device__ __forceinline__ bool stage_passes(const int32_t* tile, int base, floa
                                              const HC_CONST DevNode* nodes, const HC_CONST DevTree* trees,
                                              const float* __restrict__ leaves) {
   double acc = 0.0;
+  const int first = st.first, count = st.count;
+  const float sthr = st.thr;
   if (!TREE) {
-    for (int t = 0; t < st.count; t++) {                      // A.8 predictOrderedStump
-      const HC_CONST DevNode& n = nodes[st.first + t];
-      const float v = feature_value(tile, base, n, vnf);
-      acc += (double)(v < n.thr ? __uint_as_float(n.a) : __uint_as_float(n.b));
+    NodeRegs cur = load_node(nodes, first);
+    for (int t = 0; t < count; t++) {                         // A.8 predictOrderedStump
+      const NodeRegs nxt = load_node(nodes, first + min(t + 1, count - 1));
+      const float v = feature_value(tile, base, cur, vnf);
+      const float thr = __uint_as_float(cur.q2[1]);
+      const float leaf = v < thr ? __uint_as_float(cur.q2[2]) : __uint_as_float(cur.q2[3]);
+      acc += (double)leaf;
+      cur = nxt;
     }
   } else {
-    for (int t = 0; t < st.count; t++) {                      // A.9 predictOrdered
-      const HC_CONST DevTree& T = trees[st.first + t];
-      int cur = 0;                                            // children always follow their parent
-      for (int k = 0; k < T.nnodes; k++) {
-        const HC_CONST DevNode& n = nodes[T.first_node + k];
-        const float v = feature_value(tile, base, n, vnf);
-        const int nxt = v < n.thr ? (int)n.a : (int)n.b;
-        cur = (cur == k) ? nxt : cur;
+    for (int t = 0; t < count; t++) {                         // A.9 predictOrdered
+      const HC_CONST DevTree& T = trees[first + t];
+      const int fn = T.first_node, nn = T.nnodes, fl = T.first_leaf;
+      int at = 0;                                             // children always follow their parent
+      NodeRegs cur = load_node(nodes, fn);
+      for (int k = 0; k < nn; k++) {
+        const NodeRegs nxt = load_node(nodes, fn + min(k + 1, nn - 1));
+        const float v = feature_value(tile, base, cur, vnf);
+        const float thr = __uint_as_float(cur.q2[1]);
+        const int go = v < thr ? (int)cur.q2[2] : (int)cur.q2[3];
+        at = (at == k) ? go : at;
+        cur = nxt;
       }
-      acc += (double)leaves[T.first_leaf - cur];
+      acc += (double)leaves[fl - at];
     }
   }
-  return !(acc < (double)st.thr);
+  return !(acc < (double)sthr);
+}
+
+// ---- sparse mode: ONE window per wavefront, the stage's weak classifiers spread over the
+// 64 lanes.  Legal only for stages whose f64 sum is exact in every order (DevStage::exact,
+// proven on the host from the leaf values): then the order-free wave reduction gives the very
+// same double as upstream's sequential accumulation.  Removes the long serial stump chains of
+// the few windows that reach the deep stages.
+__device__ __forceinline__ float feature_value_lane(const int32_t* tile, int base, const DevNode& n, float vnf) {
+  const int s0 = tile[base + n.off[0]] - tile[base + n.off[1]] - tile[base + n.off[2]] + tile[base + n.off[3]];
+  const int s1 = tile[base + n.off[4]] - tile[base + n.off[5]] - tile[base + n.off[6]] + tile[base + n.off[7]];
+  float ret = n.w[0] * (float)s0 + n.w[1] * (float)s1;
+  if (n.w[2] != 0.0f) {
+    const int s2 = tile[base + n.off[8]] - tile[base + n.off[9]] - tile[base + n.off[10]] + tile[base + n.off[11]];
+    ret += n.w[2] * (float)s2;
+  }
+  return ret * vnf;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
 }
 
 template <bool TREE>
+__device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int base, float vnf, int first, int count,
+                                                    float sthr, int lane, const DevNode* __restrict__ nodes,
+                                                    const DevTree* __restrict__ trees,
+                                                    const float* __restrict__ leaves) {
+  double part = 0.0;
+  for (int t = lane; t < count; t += 64) {
+    if (!TREE) {
+      const DevNode n = nodes[first + t];
+      const float v = feature_value_lane(tile, base, n, vnf);
+      part += (double)(v < n.thr ? __uint_as_float(n.a) : __uint_as_float(n.b));
+    } else {
+      const DevTree T = trees[first + t];
+      int at = 0;
+      do {
+        const DevNode n = nodes[T.first_node + at];
+        const float v = feature_value_lane(tile, base, n, vnf);
+        at = v < n.thr ? (int)n.a : (int)n.b;
+      } while (at > 0);
+      part += (double)leaves[T.first_leaf - at];
+    }
+  }
+  return !(wave_sum_f64(part) < (double)sthr);
+}
+
+// LDS layout of k_cascade (words): [ tile: tile_words ][ vnf: TILE_WIN f32 ][ 2 queues: TILE_WIN u16 each ][ 4 counters ]
+constexpr int TILE_WIN = BAND_ROWS * TILE_POS;                 // windows per tile step (512)
+
+template <bool TREE>
 __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
-  extern __shared__ int32_t tile[];
+  extern __shared__ int32_t smem[];
+  int32_t* tile = smem;
+  float* vnf_t = (float*)(smem + A.tile_words);
+  uint16_t* queue = (uint16_t*)(vnf_t + TILE_WIN);             // queue[b][TILE_WIN]
+  int* cnt = (int*)(queue + 2 * TILE_WIN);                      // three rotating counters
   // XCD-aware order: workgroups b, b+8, b+16.. share an XCD/L2 -> give them adjacent bands,
   // whose staged rows overlap by win_h.
   const int nb8 = (A.nbands + 7) >> 3;
@@ -229,11 +313,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
   const int nx = L.nx, ny = L.ny;
   const uint32_t* __restrict__ I = A.sum + (size_t)frame * A.int_stride + L.int_ofs;
   const size_t grid_base = (size_t)frame * A.grid_stride + L.grid_ofs;
+  const unsigned long long key_hi = ((unsigned long long)frame << 40) | ((unsigned long long)it.level << 32);
+  const unsigned long long lt_mask = lane ? ((1ull << lane) - 1ull) : 0ull;
   bool carry[2] = {true, true};   // is position 0 of the next tile visited (per owned row)
 
   for (int gx0 = 0; gx0 < nx; gx0 += TILE_POS) {
     const int x0 = gx0 * ys;
-    __syncthreads();              // everybody is done with the previous tile
+    __syncthreads();              // everybody is done with the previous tile and its queues
     for (int r = wave; r < G.rows; r += WG_THREADS / 64) {
       const int sy = y0 + r;
       const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
@@ -245,8 +331,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
         drow[d] = (int32_t)v;
       }
     }
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     __syncthreads();
 
+    // ---- stage 0 on every position; x-skip chain; survivors -> queue 0
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int rr = wave + 4 * j;
@@ -256,36 +344,89 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
       const float vnf = valid ? A.vnf[grid_base + (size_t)gy * nx + gx] : 0.f;
       const bool evaluable = vnf > 0.f;
       const int base = rr * ys * G.pitch + lane;
-
-      // stage 0 on every position of the row segment
       const bool pass0 = stage_passes<TREE>(tile, base, vnf, stages[0], nodes, trees, A.leaves);
       const bool f = evaluable && !pass0;                      // "fails stage 0 if evaluated"
 
       // A.7 in closed form: position k is visited iff its distance to the nearest anchor
       // (k == row start, or f[k-1] == 0) at or left of it is even.
       const unsigned long long fm = __ballot(f);
-      const unsigned long long below = lane ? (~fm & ((1ull << lane) - 1ull)) : 0ull;
+      const unsigned long long below = ~fm & lt_mask;
       const int anchor = below ? 64 - __clzll((long long)below) : (carry[j] ? 0 : 1);
       const bool visited = ((lane - anchor) & 1) == 0;
       const unsigned long long vm = __ballot(visited);
       carry[j] = !(((vm & fm) >> 63) & 1ull);
 
-      bool alive = valid && visited && evaluable && pass0;
-      int passed = pass0 ? 1 : 0;
-      for (int s = 1; s < A.nstages; s++) {
-        if (!__any(alive)) break;
-        const bool ok = stage_passes<TREE>(tile, base, vnf, stages[s], nodes, trees, A.leaves);
-        alive = alive && ok;
-        passed += alive ? 1 : 0;
+      const bool surv = valid && visited && evaluable && pass0;
+      vnf_t[rr * TILE_POS + lane] = vnf;
+      const unsigned long long sm = __ballot(surv);
+      if (sm) {
+        int off = 0;
+        if (lane == 0) off = atomicAdd(&cnt[0], __popcll(sm));
+        off = __shfl(off, 0, 64);
+        if (surv) queue[off + __popcll(sm & lt_mask)] = (uint16_t)(rr * TILE_POS + lane);
       }
-      if (alive) {                                              // A.6c: raw candidate
+      if (A.taps && valid && visited && !surv)
+        A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? 0 : -1);
+    }
+    __syncthreads();
+
+    // ---- stages 1.. on the compacted survivor list, re-compacted after every stage.
+    // queue (s-1)&1 is read, queue s&1 is written; counters rotate over three slots so that the
+    // slot zeroed during stage s is neither the one read nor the one being appended to.
+    int s = 1;
+    for (; s < A.nstages; s++) {
+      const int n = cnt[(s - 1) % 3];
+      if (n == 0) break;                                        // uniform: read after the barrier
+      const uint16_t* qin = queue + ((s - 1) & 1) * TILE_WIN;
+      uint16_t* qout = queue + (s & 1) * TILE_WIN;
+      int* cout = &cnt[s % 3];
+      if (threadIdx.x == 0) cnt[(s + 1) % 3] = 0;
+      const int sfirst = stages[s].first, scount = stages[s].count;
+      const float sthr = stages[s].thr;
+      if (n <= A.sparse_max && stages[s].exact) {
+        // few survivors: one window per wavefront, lanes across the stage's weak classifiers
+        const DevNode* nodes_g = ys == 1 ? A.nodes1 : A.nodes2;
+        for (int i = wave; i < n; i += WG_THREADS / 64) {
+          const int pos = qin[i];
+          const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
+          const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_t[pos], sfirst, scount, sthr, lane, nodes_g,
+                                                    A.trees, A.leaves);
+          if (lane == 0) {
+            if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
+            else if (A.taps) A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
+          }
+        }
+      } else {
+        for (int i0 = wave * 64; i0 < n; i0 += WG_THREADS) {
+          const int i = i0 + lane;
+          const bool active = i < n;
+          const int pos = active ? qin[i] : 0;
+          const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
+          const bool ok = stage_passes<TREE>(tile, base, vnf_t[pos], stages[s], nodes, trees, A.leaves);
+          const bool surv = active && ok;
+          const unsigned long long sm = __ballot(surv);
+          if (sm) {
+            int off = 0;
+            if (lane == 0) off = atomicAdd(cout, __popcll(sm));
+            off = __shfl(off, 0, 64);
+            if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
+          }
+          if (A.taps && active && !ok)
+            A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
+        }
+      }
+      __syncthreads();
+    }
+    if (s == A.nstages) {                                       // queue (s-1)&1 holds the accepted windows
+      const int n = cnt[(s - 1) % 3];
+      const uint16_t* qin = queue + ((s - 1) & 1) * TILE_WIN;
+      for (int i = threadIdx.x; i < n; i += WG_THREADS) {       // A.6c: raw candidates
+        const int pos = qin[i];
+        const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
         const unsigned int slot = atomicAdd(A.cand_count, 1u);
-        if (slot < A.cand_cap)
-          A.cand[slot] = ((unsigned long long)frame << 40) | ((unsigned long long)it.level << 32) |
-                         ((unsigned long long)gy << 16) | (unsigned long long)gx;
+        if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+        if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
       }
-      if (A.taps && valid && visited)
-        A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? passed : -1);
     }
   }
 }
