@@ -5,9 +5,9 @@
 
 namespace hc {
 
-// Cascade-kernel tiling: one workgroup (4 wavefronts of 64) owns BAND_ROWS grid rows of a
-// pyramid level and walks them left to right in steps of TILE_POS grid positions.
-constexpr int BAND_ROWS = 8;
+// Cascade-kernel tiling: one workgroup (4 wavefronts of 64) owns a band of 8/16/32 grid rows
+// of a pyramid level (chosen per ystep class at configure time) and walks it left to right in
+// steps of TILE_POS grid positions.
 constexpr int TILE_POS = 64;
 constexpr int WG_THREADS = 256;
 

@@ -72,10 +72,13 @@ struct hc_context {
   hc::Plan plan;
   bool configured = false;
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
-  hc::TileGeom g1{}, g2{};
-  size_t lds_bytes = 0;
-  int tile_words = 0;
+  // cascade-kernel tiling per ystep class (index 0: ystep 1, index 1: ystep 2)
+  int band_rows[2] = {16, 8};
+  hc::TileGeom geom[2] = {};
+  size_t lds_bytes[2] = {0, 0};
+  int tile_words[2] = {0, 0};
   int sparse_max = 32;
+  int row_stages = 1;
 
   // device
   uint8_t* d_frames = nullptr;   // staging for the host-input path
@@ -88,8 +91,8 @@ struct hc_context {
   uint32_t* d_xtab = nullptr;
   uint32_t* d_ytab = nullptr;
   hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
-               *d_band_items = nullptr;
-  hc::DevNode *d_nodes1 = nullptr, *d_nodes2 = nullptr;
+               *d_band_items[2] = {nullptr, nullptr};
+  hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
   hc::DevStage* d_stages = nullptr;
   hc::DevTree* d_trees = nullptr;
   float* d_leaves = nullptr;
@@ -109,11 +112,11 @@ struct hc_context {
 
   void free_workspace() {
     void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
-                    d_row_items, d_col_items, d_var_items, d_band_items, d_cand, d_count};
+                    d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_cand, d_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d_frames = d_pyr = nullptr; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
     d_xtab = d_ytab = nullptr;
-    d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items = nullptr;
+    d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items[0] = d_band_items[1] = nullptr;
     d_cand = nullptr; d_count = nullptr;
     if (h_cand) (void)hipHostFree(h_cand);
     if (h_count) (void)hipHostFree(h_count);
@@ -125,10 +128,10 @@ struct hc_context {
 namespace {
 
 // LDS tile geometry + per-geometry corner offsets of every node
-hc::TileGeom make_geom(const hc::Model& m, int ystep) {
+hc::TileGeom make_geom(const hc::Model& m, int ystep, int band_rows) {
   hc::TileGeom g{};
   g.cols = (hc::TILE_POS - 1) * ystep + m.win_w + 1;
-  g.rows = (hc::BAND_ROWS - 1) * ystep + m.win_h + 1;
+  g.rows = (band_rows - 1) * ystep + m.win_h + 1;
   if (ystep == 1) { g.half = 0; g.pitch = g.cols; }
   else { g.half = (g.cols + 1) / 2; g.pitch = 2 * g.half; }
   return g;
@@ -195,16 +198,17 @@ bool stage_sum_is_exact(const hc::Model& m, const hc::ModelStage& s) {
 
 int upload_model(hc_context* c) {
   const hc::Model& m = c->casc->model;
-  c->g1 = make_geom(m, 1);
-  c->g2 = make_geom(m, 2);
-  const size_t words = std::max((size_t)c->g1.pitch * c->g1.rows, (size_t)c->g2.pitch * c->g2.rows);
-  if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
-  c->tile_words = (int)words;
-  // tile | vnf[512] f32 | 2 queues x 512 u16 | 4 counters   (k_cascade LDS layout)
-  c->lds_bytes = words * 4 + (size_t)hc::BAND_ROWS * hc::TILE_POS * (4 + 2 * 2) + 16;
-  std::vector<hc::DevNode> n1, n2;
-  build_nodes(m, c->g1, 1, n1);
-  build_nodes(m, c->g2, 2, n2);
+  std::vector<hc::DevNode> nd[2];
+  for (int k = 0; k < 2; k++) {
+    const int ystep = k + 1;
+    c->geom[k] = make_geom(m, ystep, c->band_rows[k]);
+    const size_t words = (size_t)c->geom[k].pitch * c->geom[k].rows;
+    if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
+    c->tile_words[k] = (int)words;
+    // k_cascade LDS layout: tile | 2 queues x band_rows*64 u16 | 3 counters (+pad)
+    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * 2 * 2 + 16;
+    build_nodes(m, c->geom[k], ystep, nd[k]);
+  }
   std::vector<hc::DevStage> st;
   std::vector<hc::DevTree> tr;
   for (const hc::ModelStage& s : m.stages) {
@@ -217,8 +221,8 @@ int upload_model(hc_context* c) {
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   int rc;
-  if ((rc = dev_upload(&c->d_nodes1, n1))) return rc;
-  if ((rc = dev_upload(&c->d_nodes2, n2))) return rc;
+  if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;
+  if ((rc = dev_upload(&c->d_nodes[1], nd[1]))) return rc;
   if ((rc = dev_upload(&c->d_stages, st))) return rc;
   if ((rc = dev_upload(&c->d_trees, tr))) return rc;
   if ((rc = dev_upload(&c->d_leaves, m.leaves))) return rc;
@@ -261,18 +265,21 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
-    hc::CascadeArgs A{};
-    A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
-    A.levels = c->d_levels; A.bands = c->d_band_items; A.nbands = (int)P.band_items.size();
-    A.nodes1 = c->d_nodes1; A.nodes2 = c->d_nodes2; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
-    if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) A.nstages = std::min(A.nstages, std::max(1, atoi(e_)));   // timing experiments only
-    A.trees = c->d_trees; A.leaves = c->d_leaves; A.g1 = c->g1; A.g2 = c->g2; A.tile_words = c->tile_words;
-    A.sparse_max = c->sparse_max;
-    A.cand = c->d_cand; A.cand_count = c->d_count;
-    A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
-    A.taps = c->taps_enabled ? c->d_taps : nullptr;
-    if ((e = hc::launch_cascade(s, nframes, !m.is_stump(), c->lds_bytes, A)))
-      return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
+    for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
+      hc::CascadeArgs A{};
+      A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
+      A.levels = c->d_levels; A.bands = c->d_band_items[k]; A.nbands = (int)P.band_items[k].size();
+      A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
+      if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) A.nstages = std::min(A.nstages, std::max(1, atoi(e_)));   // timing experiments only
+      A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
+      A.sparse_max = c->sparse_max;
+      A.row_stages = c->row_stages;
+      A.cand = c->d_cand; A.cand_count = c->d_count;
+      A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
+      A.taps = c->taps_enabled ? c->d_taps : nullptr;
+      if ((e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->lds_bytes[k], A)))
+        return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
+    }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
   }
   HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
@@ -367,7 +374,15 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   for (auto& e : ctx->ev) {
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
-  if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knob
+  if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knobs
+  if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
+  if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
+  if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
+  for (int k = 0; k < 2; k++)
+    if (ctx->band_rows[k] != 8 && ctx->band_rows[k] != 16 && ctx->band_rows[k] != 32) {
+      delete ctx;
+      return set_err(HC_ERR_ARG, "band rows must be 8, 16 or 32");
+    }
   int rc = upload_model(ctx);
   if (rc != HC_OK) { hc_context_destroy(ctx); return rc; }
   *out = ctx;
@@ -379,7 +394,7 @@ void hc_context_destroy(hc_context* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   ctx->free_workspace();
-  void* ptrs[] = {ctx->d_nodes1, ctx->d_nodes2, ctx->d_stages, ctx->d_trees, ctx->d_leaves};
+  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -395,7 +410,8 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->free_workspace();
   hc::Plan& P = ctx->plan;
-  int rc = hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, P);
+  int rc = hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_rows[0],
+                          ctx->band_rows[1], P);
   if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
   for (const hc::DevLevel& L : P.levels)
     if (L.nx > 65535 || L.ny_all > 65535 || P.levels.size() > 255) return set_err(HC_ERR_UNSUPPORTED, "frame too large");
@@ -422,7 +438,8 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   if ((rc = dev_upload(&ctx->d_row_items, P.row_items))) return rc;
   if ((rc = dev_upload(&ctx->d_col_items, P.col_items))) return rc;
   if ((rc = dev_upload(&ctx->d_var_items, P.var_items))) return rc;
-  if ((rc = dev_upload(&ctx->d_band_items, P.band_items))) return rc;
+  if ((rc = dev_upload(&ctx->d_band_items[0], P.band_items[0]))) return rc;
+  if ((rc = dev_upload(&ctx->d_band_items[1], P.band_items[1]))) return rc;
   HIPCHK(hipHostMalloc((void**)&ctx->h_cand, B * ctx->cand_per_frame * sizeof(unsigned long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
   ctx->pending = 0;
@@ -527,7 +544,7 @@ int hc_plan_query(const hc_cascade* c, int rows, int cols, double scale_factor, 
                   int max_h, hc_level* levels, int cap, int* nlevels, int64_t* algorithmic_bytes) {
   if (!c || !nlevels) return set_err(HC_ERR_ARG, "null argument");
   hc::Plan P;
-  int rc = hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, P);
+  int rc = hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, 16, 8, P);
   if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
   *nlevels = (int)P.levels.size();
   if (algorithmic_bytes) *algorithmic_bytes = P.algorithmic_bytes;

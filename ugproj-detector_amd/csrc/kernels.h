@@ -16,17 +16,17 @@ struct CascadeArgs {
   const float* vnf;           // per-frame grid arrays, frame stride grid_stride elements
   size_t grid_stride;
   const DevLevel* levels;
-  const WorkItem* bands;
+  const WorkItem* bands;      // bands of ONE ystep class (all share geometry g)
   int nbands;
-  const DevNode* nodes1;      // offsets resolved for g1 (ystep 1)
-  const DevNode* nodes2;      // offsets resolved for g2 (ystep 2)
+  const DevNode* nodes;       // corner offsets resolved for g
   const DevStage* stages;
   int nstages;
   const DevTree* trees;
   const float* leaves;
-  TileGeom g1, g2;
+  TileGeom g;
+  int row_stages;             // leading stages evaluated in row form (>= 1) before survivors are compacted
   int sparse_max;             // stages with <= sparse_max survivors in a tile run in sparse mode
-  int tile_words;             // LDS words reserved for the integral tile (max over g1, g2)
+  int tile_words;             // LDS words reserved for the integral tile
   unsigned long long* cand;   // raw candidate keys: frame<<40 | level<<32 | gy<<16 | gx
   unsigned int* cand_count;
   unsigned int cand_cap;
@@ -45,6 +45,7 @@ int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel
 int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride);
-int launch_cascade(hipStream_t st, int nframes, bool tree, size_t lds_bytes, const CascadeArgs& args);
+// rows = band height in grid rows (8, 16 or 32); lds_bytes = tile + 2 queues + counters
+int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args);
 
 }  // namespace hc

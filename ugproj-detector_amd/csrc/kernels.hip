@@ -284,43 +284,52 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
   return !(wave_sum_f64(part) < (double)sthr);
 }
 
-// LDS layout of k_cascade (words): [ tile: tile_words ][ vnf: TILE_WIN f32 ][ 2 queues: TILE_WIN u16 each ][ 4 counters ]
-constexpr int TILE_WIN = BAND_ROWS * TILE_POS;                 // windows per tile step (512)
-
-template <bool TREE>
+// LDS layout of k_cascade: [ tile: tile_words x i32 ][ 2 queues: ROWS*64 x u16 each ][ 3 counters ]
+//
+// Workgroup = 4 wavefronts = one band of ROWS grid rows of one level of one frame.  It walks
+// the band left to right in steps of TILE_POS positions; per step it stages the
+// (ROWS-1)*ystep+win_h+1 by (TILE_POS-1)*ystep+win_w+1 window of the `sum` integral in LDS
+// (coalesced row loads; for ystep 2 the even and odd columns go to separate planes so that
+// lane k's corner reads are stride-1 in LDS).  Wave w owns grid rows w, w+4, .. of the band
+// for the whole walk, so the x-skip carry (A.7) stays in its registers.  Bigger ROWS = bigger
+// survivor pool per workgroup = fuller wavefronts in the middle stages, and less halo per window.
+template <bool TREE, int ROWS>
 __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
+  constexpr int TILE_WIN = ROWS * TILE_POS;
+  constexpr int NW = WG_THREADS / 64;
   extern __shared__ int32_t smem[];
   int32_t* tile = smem;
-  float* vnf_t = (float*)(smem + A.tile_words);
-  uint16_t* queue = (uint16_t*)(vnf_t + TILE_WIN);             // queue[b][TILE_WIN]
+  uint16_t* queue = (uint16_t*)(smem + A.tile_words);          // queue[2][TILE_WIN]
   int* cnt = (int*)(queue + 2 * TILE_WIN);                      // three rotating counters
-  // XCD-aware order: workgroups b, b+8, b+16.. share an XCD/L2 -> give them adjacent bands,
-  // whose staged rows overlap by win_h.
-  const int nb8 = (A.nbands + 7) >> 3;
-  const int band = (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
-  if (band >= A.nbands) return;
+  // Dispatch order: frame is the FAST grid dimension, bands (largest levels first) the slow one,
+  // so the long-running bands of every frame start first and the tail of the launch is made of
+  // the smallest bands.  With a batch that is a multiple of 8, workgroups b and b + nframes
+  // (adjacent bands of one frame, whose staged rows overlap by win_h) still share an XCD/L2.
+  const int band = blockIdx.y;
   const WorkItem it = load_item(A.bands, band);
   const HC_CONST DevLevel& L = as_const(A.levels)[it.level];
   const HC_CONST DevStage* stages = as_const(A.stages);
   const HC_CONST DevTree* trees = as_const(A.trees);
-  const int frame = blockIdx.y;
+  const HC_CONST DevNode* nodes = as_const(A.nodes);
+  const int frame = blockIdx.x;
   const int ys = L.ystep;
-  const TileGeom G = ys == 1 ? A.g1 : A.g2;
-  const HC_CONST DevNode* nodes = as_const(ys == 1 ? A.nodes1 : A.nodes2);
+  const TileGeom G = A.g;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int gy0 = it.a;
   const int y0 = gy0 * ys;
   const int nx = L.nx, ny = L.ny;
   const uint32_t* __restrict__ I = A.sum + (size_t)frame * A.int_stride + L.int_ofs;
   const size_t grid_base = (size_t)frame * A.grid_stride + L.grid_ofs;
+  const float* __restrict__ vnf_g = A.vnf + grid_base;
   const unsigned long long key_hi = ((unsigned long long)frame << 40) | ((unsigned long long)it.level << 32);
   const unsigned long long lt_mask = lane ? ((1ull << lane) - 1ull) : 0ull;
-  bool carry[2] = {true, true};   // is position 0 of the next tile visited (per owned row)
+  const int row_stages = min(A.row_stages, A.nstages);   // stages evaluated in row form before the first compaction
+  unsigned int carry = 0xffffffffu;   // bit j: is position 0 of the next tile visited, for owned row wave + 4j
 
   for (int gx0 = 0; gx0 < nx; gx0 += TILE_POS) {
     const int x0 = gx0 * ys;
     __syncthreads();              // everybody is done with the previous tile and its queues
-    for (int r = wave; r < G.rows; r += WG_THREADS / 64) {
+    for (int r = wave; r < G.rows; r += NW) {
       const int sy = y0 + r;
       const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
       int32_t* drow = tile + r * G.pitch;
@@ -336,12 +345,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
 
     // ---- stage 0 on every position; x-skip chain; survivors -> queue 0
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int rr = wave + 4 * j;
+    for (int j = 0; j < ROWS / NW; j++) {
+      const int rr = wave + NW * j;
       const int gy = gy0 + rr, gx = gx0 + lane;
       if (gy >= ny) continue;                                   // wave-uniform
       const bool valid = gx < nx;
-      const float vnf = valid ? A.vnf[grid_base + (size_t)gy * nx + gx] : 0.f;
+      const float vnf = valid ? vnf_g[(size_t)gy * nx + gx] : 0.f;
       const bool evaluable = vnf > 0.f;
       const int base = rr * ys * G.pitch + lane;
       const bool pass0 = stage_passes<TREE>(tile, base, vnf, stages[0], nodes, trees, A.leaves);
@@ -351,13 +360,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
       // (k == row start, or f[k-1] == 0) at or left of it is even.
       const unsigned long long fm = __ballot(f);
       const unsigned long long below = ~fm & lt_mask;
-      const int anchor = below ? 64 - __clzll((long long)below) : (carry[j] ? 0 : 1);
+      const int anchor = below ? 64 - __clzll((long long)below) : (((carry >> j) & 1u) ? 0 : 1);
       const bool visited = ((lane - anchor) & 1) == 0;
       const unsigned long long vm = __ballot(visited);
-      carry[j] = !(((vm & fm) >> 63) & 1ull);
+      if (((vm & fm) >> 63) & 1ull) carry &= ~(1u << j); else carry |= (1u << j);
 
-      const bool surv = valid && visited && evaluable && pass0;
-      vnf_t[rr * TILE_POS + lane] = vnf;
+      bool surv = valid && visited && evaluable && pass0;
+      if (A.taps && valid && visited && !surv)
+        A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? 0 : -1);
+      // the next stage(s) stay in row form: lanes = adjacent windows -> conflict-free LDS reads
+      // and no queue traffic while most windows are still alive
+      for (int s = 1; s < row_stages; s++) {
+        if (!__any(surv)) break;
+        const bool ok = stage_passes<TREE>(tile, base, vnf, stages[s], nodes, trees, A.leaves);
+        if (A.taps && surv && !ok) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)s;
+        surv = surv && ok;
+      }
       const unsigned long long sm = __ballot(surv);
       if (sm) {
         int off = 0;
@@ -365,44 +383,45 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
         off = __shfl(off, 0, 64);
         if (surv) queue[off + __popcll(sm & lt_mask)] = (uint16_t)(rr * TILE_POS + lane);
       }
-      if (A.taps && valid && visited && !surv)
-        A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? 0 : -1);
     }
     __syncthreads();
 
-    // ---- stages 1.. on the compacted survivor list, re-compacted after every stage.
-    // queue (s-1)&1 is read, queue s&1 is written; counters rotate over three slots so that the
-    // slot zeroed during stage s is neither the one read nor the one being appended to.
-    int s = 1;
+    // ---- remaining stages on the compacted survivor list, re-compacted after every stage.
+    // With t = s - row_stages: queue t&1 is read, queue (t+1)&1 is written; counters rotate over
+    // three slots so that the slot zeroed during a stage is neither the one read nor the one
+    // being appended to.
+    int s = row_stages;
     for (; s < A.nstages; s++) {
-      const int n = cnt[(s - 1) % 3];
+      const int t = s - row_stages;
+      const int n = cnt[t % 3];
       if (n == 0) break;                                        // uniform: read after the barrier
-      const uint16_t* qin = queue + ((s - 1) & 1) * TILE_WIN;
-      uint16_t* qout = queue + (s & 1) * TILE_WIN;
-      int* cout = &cnt[s % 3];
-      if (threadIdx.x == 0) cnt[(s + 1) % 3] = 0;
+      const uint16_t* qin = queue + (t & 1) * TILE_WIN;
+      uint16_t* qout = queue + ((t + 1) & 1) * TILE_WIN;
+      int* cout = &cnt[(t + 1) % 3];
+      if (threadIdx.x == 0) cnt[(t + 2) % 3] = 0;
       const int sfirst = stages[s].first, scount = stages[s].count;
       const float sthr = stages[s].thr;
       if (n <= A.sparse_max && stages[s].exact) {
         // few survivors: one window per wavefront, lanes across the stage's weak classifiers
-        const DevNode* nodes_g = ys == 1 ? A.nodes1 : A.nodes2;
-        for (int i = wave; i < n; i += WG_THREADS / 64) {
+        for (int i = wave; i < n; i += NW) {
           const int pos = qin[i];
+          const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
-          const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_t[pos], sfirst, scount, sthr, lane, nodes_g,
-                                                    A.trees, A.leaves);
+          const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_g[(size_t)wy * nx + wx], sfirst, scount, sthr,
+                                                    lane, A.nodes, A.trees, A.leaves);
           if (lane == 0) {
             if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
-            else if (A.taps) A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
+            else if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
           }
         }
       } else {
         for (int i0 = wave * 64; i0 < n; i0 += WG_THREADS) {
           const int i = i0 + lane;
           const bool active = i < n;
-          const int pos = active ? qin[i] : 0;
+          const int pos = active ? qin[i] : qin[0];
+          const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
-          const bool ok = stage_passes<TREE>(tile, base, vnf_t[pos], stages[s], nodes, trees, A.leaves);
+          const bool ok = stage_passes<TREE>(tile, base, vnf_g[(size_t)wy * nx + wx], stages[s], nodes, trees, A.leaves);
           const bool surv = active && ok;
           const unsigned long long sm = __ballot(surv);
           if (sm) {
@@ -411,15 +430,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
             off = __shfl(off, 0, 64);
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
-          if (A.taps && active && !ok)
-            A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
+          if (A.taps && active && !ok) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
         }
       }
       __syncthreads();
     }
-    if (s == A.nstages) {                                       // queue (s-1)&1 holds the accepted windows
-      const int n = cnt[(s - 1) % 3];
-      const uint16_t* qin = queue + ((s - 1) & 1) * TILE_WIN;
+    if (s == A.nstages) {                                       // the last written queue holds the accepted windows
+      const int t = s - row_stages;
+      const int n = cnt[t % 3];
+      const uint16_t* qin = queue + (t & 1) * TILE_WIN;
       for (int i = threadIdx.x; i < n; i += WG_THREADS) {       // A.6c: raw candidates
         const int pos = qin[i];
         const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
@@ -474,15 +493,23 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
   return 0;
 }
 
-int launch_cascade(hipStream_t st, int nframes, bool tree, size_t lds_bytes, const CascadeArgs& args) {
-  if (args.nbands == 0 || nframes == 0) return 0;
-  const int gx = ((args.nbands + 7) / 8) * 8;
-  if (tree)
-    hipLaunchKernelGGL(k_cascade<true>, dim3(gx, nframes), dim3(WG_THREADS), lds_bytes, st, args);
-  else
-    hipLaunchKernelGGL(k_cascade<false>, dim3(gx, nframes), dim3(WG_THREADS), lds_bytes, st, args);
+template <bool TREE>
+static int launch_cascade_rows(hipStream_t st, int nframes, int rows, size_t lds_bytes, const CascadeArgs& args) {
+  const dim3 grid(nframes, args.nbands), block(WG_THREADS);
+  switch (rows) {
+    case 8: hipLaunchKernelGGL((k_cascade<TREE, 8>), grid, block, lds_bytes, st, args); break;
+    case 16: hipLaunchKernelGGL((k_cascade<TREE, 16>), grid, block, lds_bytes, st, args); break;
+    case 32: hipLaunchKernelGGL((k_cascade<TREE, 32>), grid, block, lds_bytes, st, args); break;
+    default: return (int)hipErrorInvalidValue;
+  }
   HC_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args) {
+  if (args.nbands == 0 || nframes == 0) return 0;
+  return tree ? launch_cascade_rows<true>(st, nframes, rows, lds_bytes, args)
+              : launch_cascade_rows<false>(st, nframes, rows, lds_bytes, args);
 }
 
 }  // namespace hc

@@ -45,8 +45,10 @@ void build_resize_table(int src, int dst, std::vector<uint32_t>& out) {
 }
 
 int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
-               int max_w, int max_h, Plan& p) {
+               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p) {
   p = Plan{};
+  p.band_rows[0] = band_rows_ystep1;
+  p.band_rows[1] = band_rows_ystep2;
   p.rows = rows; p.cols = cols; p.scale_factor = scale_factor;
   p.min_w = min_w; p.min_h = min_h;
   if (!(scale_factor > 1.0) || rows <= 0 || cols <= 0) return HC_ERR_ARG;
@@ -128,8 +130,9 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
     for (int x0 = 0; x0 < L.w; x0 += WG_THREADS) p.col_items.push_back(WorkItem{li, x0, 0});
     const int npos = L.nx * L.ny;
     for (int i0 = 0; i0 < npos; i0 += WG_THREADS) p.var_items.push_back(WorkItem{li, i0, 0});
+    const int cls = L.ystep == 1 ? 0 : 1;
     if (L.nx > 0)
-      for (int gy0 = 0; gy0 < L.ny; gy0 += BAND_ROWS) p.band_items.push_back(WorkItem{li, gy0, 0});
+      for (int gy0 = 0; gy0 < L.ny; gy0 += p.band_rows[cls]) p.band_items[cls].push_back(WorkItem{li, gy0, 0});
   }
   return HC_OK;
 }

@@ -23,7 +23,8 @@ struct Plan {
   std::vector<WorkItem> row_items;    // 4 rows per block
   std::vector<WorkItem> col_items;    // 256 columns per block
   std::vector<WorkItem> var_items;    // 256 grid positions of one grid row segment per block
-  std::vector<WorkItem> band_items;   // cascade kernel: one band of BAND_ROWS grid rows of one level
+  std::vector<WorkItem> band_items[2];  // cascade kernel: bands of band_rows[c] grid rows; c = 0: ystep 1, 1: ystep 2
+  int band_rows[2] = {16, 8};
 
   int64_t pyr_bytes = 0;    // per frame
   int64_t int_words = 0;    // per frame, per integral array
@@ -34,7 +35,7 @@ struct Plan {
 // Fills `p`. Returns HC_OK; an image smaller than the window or an empty ladder yields a
 // plan with zero levels (detectMultiScale then returns no rectangles).
 int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
-               int max_w, int max_h, Plan& p);
+               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p);
 
 // (ofs << 9) | c1 for every destination index of a src -> dst exact bilinear resize
 void build_resize_table(int src, int dst, std::vector<uint32_t>& out);
