@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--cascade", default="alt")
     ap.add_argument("--cpu-sample", type=int, default=32, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="1: both pipeline slots on one stream (clean per-kernel times); 2: a stream per slot")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,22 +89,49 @@ def main():
     d_frames = torch.from_numpy(frames_np).to(dev)
     torch.cuda.synchronize()
 
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = pkg.Context(casc, device=local_rank, stream=stream)
-    ctx.configure(ROWS, COLS, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
-                  max_batch=B, cand_capacity=4096)
+    # Two contexts (workspaces) on the same stream: batch i+1 is enqueued before batch i is
+    # waited for, so the host-side candidate decode / rectangle grouping / record packing of
+    # batch i overlaps the kernels of batch i+1.  Every step still does all of its work.
+    if args.streams == 1:
+        # one explicit (non-default) stream shared by both contexts: kernels of consecutive batches
+        # run back to back, never concurrently, so the per-kernel HIP-event times are clean
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        stream = None   # each context owns a stream: kernels of batch i+1 may overlap the tail of batch i
+    ctxs = []
+    for _ in range(2):
+        c = pkg.Context(casc, device=local_rank, stream=stream)
+        c.configure(ROWS, COLS, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
+                    max_batch=B, cand_capacity=4096)
+        ctxs.append(c)
+    ctx = ctxs[0]
     alg_bytes = ctx.algorithmic_bytes()
 
-    def step(global_step):
-        ctx.enqueue_device(d_frames.data_ptr(), B)
-        boxes = ctx.wait(B)
+    def finish(c, global_step):
+        boxes = c.wait(B)
         lo = (global_step * world + rank) * B
         rec = shard.pack_records(range(lo, lo + B), boxes)
         allrec = shard.gather_records(rec, dev if world > 1 else None)
         return boxes, allrec
 
-    for i in range(args.warmup):
-        step(i)
+    def run_steps(nsteps, on_done=None):
+        """nsteps batches, software-pipelined two deep; returns the results of the last one."""
+        res = None
+        ctxs[0].enqueue_device(d_frames.data_ptr(), B)
+        for i in range(nsteps):
+            if i + 1 < nsteps:
+                ctxs[(i + 1) & 1].enqueue_device(d_frames.data_ptr(), B)
+            res = finish(ctxs[i & 1], i)
+            if on_done:
+                on_done(ctxs[i & 1])
+        return res
+
+    def step(global_step):
+        ctx.enqueue_device(d_frames.data_ptr(), B)
+        return finish(ctx, global_step)
+
+    run_steps(args.warmup)
 
     # ---- parity of what is being timed: first `ndist` frames of this rank against the oracle (rank 0 only)
     parity = None
@@ -123,8 +152,14 @@ def main():
         step(0)
 
     timing = not args.no_timing_events
-    ctx.enable_timing(timing)
+    for c in ctxs:
+        c.enable_timing(timing)
     kernel_ms = {}
+
+    def collect(c):
+        if timing:
+            for k, v in c.kernel_ms().items():
+                kernel_ms[k] = kernel_ms.get(k, 0.0) + v
 
     def barrier():
         if world > 1:
@@ -133,18 +168,15 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-        if timing:
-            for k, v in ctx.kernel_ms().items():
-                kernel_ms[k] = kernel_ms.get(k, 0.0) + v
+    run_steps(args.steps, collect)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ctx.enable_timing(False)
+    for c in ctxs:
+        c.enable_timing(False)
 
     if rank == 0:
         fps = world * B * args.steps / elapsed

@@ -197,10 +197,13 @@ class Context:
 
     def wait(self, nframes=None, capacity=1 << 16):
         nframes = nframes if nframes is not None else self._n
-        out = np.zeros((capacity, 4), np.int32)
+        if getattr(self, "_out", None) is None or len(self._out) < capacity:
+            self._out = np.empty((capacity, 4), np.int32)
+        out = self._out
         ofs = np.zeros(nframes + 1, np.int32)
         _check(lib.hc_detect_batch_wait(self._h, out.ctypes.data, capacity, ofs.ctypes.data))
-        return [out[ofs[i]:ofs[i + 1]].copy() for i in range(nframes)]
+        allb = out[:ofs[nframes]].copy()
+        return [allb[ofs[i]:ofs[i + 1]] for i in range(nframes)]
 
     def raw_candidates(self, nframes, capacity=1 << 20):
         out = np.zeros((capacity, 4), np.int32)

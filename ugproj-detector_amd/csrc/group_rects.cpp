@@ -26,16 +26,26 @@ void group_rectangles(std::vector<hc_rect>& rects, int group_threshold, double e
   if (group_threshold <= 0 || rects.empty()) return;
   const int n = (int)rects.size();
 
-  // equivalence classes = connected components of the similarity graph (disjoint sets by size)
-  std::vector<int> up(n), sz(n, 1);
+  // equivalence classes = connected components of the similarity graph (disjoint sets by size).
+  // Only pairs that can be similar are tested: similar(p, q) needs |p.x - q.x| <= delta and
+  // delta <= eps/2 * (p.width + p.height), so in x-sorted order the partners of p that follow it
+  // lie within that bound.  The set of edges found is exactly the set of similar pairs.
+  std::vector<int> up(n), sz(n, 1), byx(n);
   std::iota(up.begin(), up.end(), 0);
+  std::iota(byx.begin(), byx.end(), 0);
+  std::sort(byx.begin(), byx.end(), [&](int a, int b) { return rects[a].x < rects[b].x; });
   auto root = [&](int v) {
     while (up[v] != v) { up[v] = up[up[v]]; v = up[v]; }
     return v;
   };
-  for (int i = 0; i < n; i++) {
-    for (int j = i + 1; j < n; j++) {
-      if (!similar(rects[i], rects[j], eps)) continue;
+  for (int ia = 0; ia < n; ia++) {
+    const int i = byx[ia];
+    const hc_rect& p = rects[i];
+    const double reach = eps * (p.width + p.height) * 0.5;
+    for (int ib = ia + 1; ib < n; ib++) {
+      const int j = byx[ib];
+      if ((double)(rects[j].x - p.x) > reach) break;
+      if (!similar(p, rects[j], eps)) continue;
       int a = root(i), b = root(j);
       if (a == b) continue;
       if (sz[a] < sz[b]) std::swap(a, b);

@@ -12,7 +12,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -56,6 +61,60 @@ int dev_upload(T** p, const std::vector<T>& v) {
 }
 
 }  // namespace
+
+// Small persistent worker pool for the per-frame host post-processing (candidate decode +
+// rectangle grouping): frames are independent, so a batch is a parallel-for over frames.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int nthreads) {
+    for (int i = 0; i < nthreads; i++) workers_.emplace_back([this] { loop(); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> l(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  // calls fn(i) for i in [0, n), on the pool plus the calling thread; returns when all are done
+  void parallel_for(int n, const std::function<void(int)>& fn) {
+    if (n <= 0) return;
+    { std::lock_guard<std::mutex> l(mu_); fn_ = &fn; n_ = n; next_ = 0; active_ = (int)workers_.size(); ++gen_; }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> l(mu_);
+    done_.wait(l, [this] { return active_ == 0; });
+    fn_ = nullptr;
+  }
+
+ private:
+  void drain() {
+    for (;;) {
+      const int i = next_.fetch_add(1);
+      if (i >= n_) break;
+      (*fn_)(i);
+    }
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      drain();
+      { std::lock_guard<std::mutex> l(mu_); if (--active_ == 0) done_.notify_all(); }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, active_ = 0;
+  unsigned long long gen_ = 0;
+  bool stop_ = false;
+};
 
 struct hc_cascade {
   hc::Model model;
@@ -109,6 +168,8 @@ struct hc_context {
   float last_ms[HC_NKERNELS] = {};
   std::vector<hc_rect> last_raw;
   std::vector<int32_t> last_raw_ofs;
+  std::unique_ptr<WorkerPool> pool;   // host post-processing workers (created on first multi-frame wait)
+  int host_threads = 8;
 
   void free_workspace() {
     void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
@@ -375,6 +436,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
   if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knobs
+  if (const char* e_ = getenv("HC_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
   if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
@@ -497,13 +559,22 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
   // canonical single-thread order: frame -> scale -> y -> x  == ascending key
   std::sort(ctx->h_cand, ctx->h_cand + count);
   const hc::Plan& P = ctx->plan;
-  ctx->last_raw.reserve(count);
-  size_t i = 0;
-  int total = 0;
-  std::vector<hc_rect> grp;
-  for (int f = 0; f < nframes; f++) {
-    grp.clear();
-    for (; i < count && (int)(ctx->h_cand[i] >> 40) == f; i++) {
+  // frame boundaries inside the sorted key list
+  std::vector<size_t> first(nframes + 1, count);
+  {
+    size_t i = 0;
+    for (int f = 0; f < nframes; f++) {
+      first[f] = i;
+      while (i < count && (int)(ctx->h_cand[i] >> 40) == f) i++;
+    }
+    first[nframes] = i;
+  }
+  ctx->last_raw.resize(count);
+  std::vector<std::vector<hc_rect>> grouped(nframes);
+  auto do_frame = [&](int f) {
+    std::vector<hc_rect>& grp = grouped[f];
+    grp.reserve(first[f + 1] - first[f]);
+    for (size_t i = first[f]; i < first[f + 1]; i++) {
       const unsigned long long k = ctx->h_cand[i];
       const hc::DevLevel& L = P.levels[(k >> 32) & 0xFF];
       const int gy = (int)((k >> 16) & 0xFFFF), gx = (int)(k & 0xFFFF);
@@ -511,13 +582,22 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
       const hc_rect r{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale),
                       (int)std::nearbyintf((float)(gy * L.ystep) * L.scale), L.win_w, L.win_h};
       grp.push_back(r);
+      ctx->last_raw[i] = r;
     }
-    ctx->last_raw.insert(ctx->last_raw.end(), grp.begin(), grp.end());
-    ctx->last_raw_ofs[f + 1] = (int32_t)ctx->last_raw.size();
     hc::group_rectangles(grp, ctx->min_neighbors, 0.2);     // GROUP_EPS upstream
+  };
+  if (nframes >= 4 && count >= 512 && ctx->host_threads > 1) {
+    if (!ctx->pool) ctx->pool.reset(new WorkerPool(ctx->host_threads - 1));
+    ctx->pool->parallel_for(nframes, do_frame);
+  } else {
+    for (int f = 0; f < nframes; f++) do_frame(f);
+  }
+  int total = 0;
+  for (int f = 0; f < nframes; f++) {
+    ctx->last_raw_ofs[f + 1] = (int32_t)first[f + 1];
     offsets[f] = total;
-    if (total + (int)grp.size() > out_capacity) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
-    for (const hc_rect& r : grp) out[total++] = r;
+    if (total + (int)grouped[f].size() > out_capacity) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
+    for (const hc_rect& r : grouped[f]) out[total++] = r;
   }
   offsets[nframes] = total;
   return HC_OK;
