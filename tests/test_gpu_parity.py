@@ -201,3 +201,100 @@ def test_full_size_720p_alt(pkg, oracle, synth):
         assert np.array_equal(raws[f], raw)
         assert np.array_equal(got[f], grouped)
     assert len(got[0]) >= 5
+
+
+def test_cpp_shim_matches_oracle(pkg, oracle, synth, tmp_path):
+    """The C++ cv::CascadeClassifier stand-in (hip_cascade/cascade_classifier.hpp), driven exactly
+    like reference src/tracker/detector.cc:25-31, prints the oracle's boxes."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "shim_demo")
+    frame, _ = synth.planted(240, 320, synth.frame_seed(0), nfaces=3, min_size=40, max_size=110)
+    f = tmp_path / "frame.u8"
+    frame.tofile(f)
+    for name in ("alt", "alt2"):
+        r = subprocess.run([demo, oracle.cascade_path(name), str(f), "240", "320", "1.1"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
+        want, _ = oracle.OracleCascade(oracle.cascade_path(name)).detect(frame, 1.1, 2, (30, 30))
+        assert np.array_equal(got, want) and len(want) > 0
+
+
+def test_device_resident_input(pkg, oracle, synth):
+    """hc_detect_batch_enqueue on frames that already live in HBM (torch only provides the memory)."""
+    import torch
+    path = oracle.cascade_path("alt")
+    casc = pkg.Cascade(path)
+    frames = np.stack([synth.planted(180, 240, synth.frame_seed(i), nfaces=2, min_size=40, max_size=80)[0]
+                       for i in range(3)])
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ctx = pkg.Context(casc)
+    ctx.configure(180, 240, 1.1, 2, (30, 30), (0, 0), max_batch=4)
+    ctx.enqueue_device(d.data_ptr(), 3)
+    got = ctx.wait(3)
+    host = ctx.detect_host(frames)
+    oc = oracle.OracleCascade(path)
+    for f in range(3):
+        want, _ = oc.detect(frames[f], 1.1, 2, (30, 30))
+        assert np.array_equal(got[f], want) and np.array_equal(host[f], want)
+
+
+def test_candidate_overflow_is_reported(pkg, oracle, synth):
+    casc = pkg.Cascade(oracle.cascade_path("alt"))
+    fr, _ = synth.planted(240, 320, synth.frame_seed(0), nfaces=3, min_size=40, max_size=110)
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=4)
+    ctx.enqueue_host(fr[None])
+    with pytest.raises(pkg.HipCascadeError) as e:
+        ctx.wait(1)
+    assert e.value.code == -8                      # HC_ERR_CAND_OVERFLOW: loud, never silently truncated
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=4096)
+    want, _ = oracle.OracleCascade(oracle.cascade_path("alt")).detect(fr, 1.1, 2, (30, 30))
+    assert np.array_equal(ctx.detect_host(fr[None])[0], want)
+
+
+def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf):
+    """Write an HCC1 file with the first `nstages` stages of a reference cascade; optionally make
+    one deep-stage leaf tiny so that the stage's f64 sum is no longer provably exact."""
+    import struct
+    import np_oracle_path  # noqa: F401
+    import np_oracle as npo
+    c = npo.load_hcc(oracle.cascade_path(name))
+    ntr = int(c.stage_ntrees[:nstages].sum())
+    nnd = int(c.tree_nnodes[:ntr].sum())
+    nlf = nnd + ntr
+    leaves = c.leaves[:nlf].copy()
+    if poison_leaf:
+        leaves[nlf - 3] = np.float32(1e-30)
+    out = bytearray(b"HCC1") + struct.pack("<7i", c.win_w, c.win_h, nstages, ntr, nnd, nlf, 0)
+    for i in range(nstages):
+        out += struct.pack("<d3i", float(c.stage_thr_raw[i]), int(c.stage_ntrees[i]), -1, -1)
+    for i in range(ntr):
+        out += struct.pack("<i", int(c.tree_nnodes[i]))
+    for i in range(nnd):
+        out += struct.pack("<12b", *[int(v) for v in c.rects[i].ravel()])
+        out += struct.pack("<3f", *[float(v) for v in c.weights[i]])
+        out += struct.pack("<f3i", float(c.node_thr[i]), int(c.node_left[i]), int(c.node_right[i]), 0)
+    out += leaves.astype("<f4").tobytes()
+    p = tmp_path / ("%s_%d_%d.hcc" % (name, nstages, int(poison_leaf)))
+    p.write_bytes(bytes(out))
+    return str(p)
+
+
+@pytest.mark.parametrize("name", ["alt", "alt2"])
+@pytest.mark.parametrize("poison", [False, True])
+def test_sparse_mode_and_its_ordered_fallback(pkg, oracle, synth, tmp_path, name, poison):
+    """Deep stages with few survivors run stump-parallel with an order-free f64 reduction, which is
+    only legal when the stage's leaf sum is exact in f64.  A cascade whose last stage carries a
+    1e-30 leaf breaks that proof: the kernel must take the ordered path there and still match."""
+    path = _truncated_cascade(oracle, tmp_path, name, 8, poison)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr, _ = synth.planted(240, 320, synth.frame_seed(4), nfaces=3, min_size=40, max_size=110)
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), 1, 1 << 15)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(fr[None])
+    grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
+    assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
+    assert len(raw) > 0

@@ -3,7 +3,7 @@
 import csv, glob, sys, collections
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in sorted(glob.glob(root + "/*/*/*counter_collection.csv")):
+for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

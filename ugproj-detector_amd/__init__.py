@@ -16,6 +16,14 @@ import os
 
 import numpy as np
 
+try:
+    # PyTorch-ROCm bundles its own libamdhip64.so.7.  Whoever loads first wins the SONAME, and a
+    # process must never hold two HIP runtimes: import torch (if present) BEFORE our library so
+    # both bind the same one and device pointers can be shared (bench.py, device-input tests).
+    import torch  # noqa: F401
+except ImportError:      # pure C++/ctypes use: the system ROCm runtime is used
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhip_cascade.so")
 

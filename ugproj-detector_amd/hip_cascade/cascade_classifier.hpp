@@ -1,0 +1,113 @@
+// cascade_classifier.hpp -- C++ host-side mirror of the reference's operator interface for
+// the hot path: a class with the cv::CascadeClassifier spelling the reference compiles
+// against (OpenCV 2.4 generation), backed by the C ABI in
+// include/hip_cascade.h.
+//
+//   reference src/file_io.h:38            cv::CascadeClassifier cascade_;
+//   reference src/file_io.cc:11           cascade_.load(path)                  -> load()
+//   reference src/tracker/detector.h:17   cv::CascadeClassifier& cascade;
+//   reference src/tracker/detector.cc:25  cascade.detectMultiScale(gray, faces, scale, 2,
+//                                           0|CASCADE_SCALE_IMAGE, Size(30,30)) -> detectMultiScale()
+//
+// With OpenCV headers present (the reference's own build), cv::Mat / cv::Rect / cv::Size are
+// used directly, so swapping `cv::CascadeClassifier` for `hip_cascade::CascadeClassifier` in
+// those two declarations is the whole integration.  Without OpenCV (this
+// repository's build and tests) layout-compatible PODs stand in.
+//
+// Error behaviour mirrors OpenCV: load() returns false on failure; detectMultiScale() throws
+// on scaleFactor <= 1 or a non-8-bit single-channel image (cv::Exception upstream, which the
+// reference never catches: src/tracker/main.cc:14-41) and on any device failure -- there is
+// no CPU fallback to hide behind.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/hip_cascade.h"
+
+#if defined(HIP_CASCADE_WITH_OPENCV) || (defined(__has_include) && __has_include(<opencv2/core/core.hpp>))
+#include <opencv2/core/core.hpp>
+#define HIP_CASCADE_HAVE_OPENCV 1
+#endif
+
+namespace hip_cascade {
+
+#ifdef HIP_CASCADE_HAVE_OPENCV
+using Rect = cv::Rect;
+using Size = cv::Size;
+using Mat = cv::Mat;
+inline const unsigned char* mat_data(const Mat& m) { return m.data; }
+inline int mat_rows(const Mat& m) { return m.rows; }
+inline int mat_cols(const Mat& m) { return m.cols; }
+inline size_t mat_step(const Mat& m) { return m.step; }
+inline bool mat_is_u8c1(const Mat& m) { return m.type() == CV_8UC1; }
+#else
+struct Rect { int x = 0, y = 0, width = 0, height = 0; };
+struct Size {
+  int width = 0, height = 0;
+  Size() = default;
+  Size(int w, int h) : width(w), height(h) {}
+};
+// minimal stand-in for an 8UC1 cv::Mat view (no ownership)
+struct Mat {
+  const unsigned char* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;
+  Mat() = default;
+  Mat(int r, int c, const unsigned char* d, size_t s = 0) : data(d), rows(r), cols(c), step(s ? s : (size_t)c) {}
+};
+inline const unsigned char* mat_data(const Mat& m) { return m.data; }
+inline int mat_rows(const Mat& m) { return m.rows; }
+inline int mat_cols(const Mat& m) { return m.cols; }
+inline size_t mat_step(const Mat& m) { return m.step; }
+inline bool mat_is_u8c1(const Mat&) { return true; }
+#endif
+static_assert(sizeof(Rect) == sizeof(hc_rect), "Rect must be layout-compatible with hc_rect");
+
+enum { CASCADE_SCALE_IMAGE = 2 };   // accepted and ignored, as OpenCV >= 4 does for this path
+
+class CascadeClassifier {
+ public:
+  CascadeClassifier() = default;
+  explicit CascadeClassifier(const std::string& filename) { load(filename); }
+  CascadeClassifier(const CascadeClassifier&) = delete;
+  CascadeClassifier& operator=(const CascadeClassifier&) = delete;
+  ~CascadeClassifier() { hc_cascade_free(h_); }
+
+  bool load(const std::string& filename) {
+    hc_cascade_free(h_);
+    h_ = nullptr;
+    return hc_cascade_load(filename.c_str(), &h_) == HC_OK;
+  }
+  bool empty() const { return h_ == nullptr; }
+
+  void detectMultiScale(const Mat& image, std::vector<Rect>& objects, double scaleFactor = 1.1, int minNeighbors = 3,
+                        int flags = 0, Size minSize = Size(), Size maxSize = Size()) {
+    objects.clear();                                    // upstream clears the output first
+    if (empty()) return;                                // upstream: empty classifier -> no detections
+    if (!(scaleFactor > 1.0) || !mat_is_u8c1(image) || !mat_data(image))
+      throw std::invalid_argument("hip_cascade::detectMultiScale: scaleFactor > 1 and an 8-bit 1-channel image required");
+    int cap = 1024;
+    for (;;) {
+      objects.resize(cap);
+      int n = 0;
+      const int rc = hc_detect_multiscale(h_, mat_data(image), mat_rows(image), mat_cols(image), mat_step(image),
+                                          scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
+                                          maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
+                                          cap, &n);
+      if (rc == HC_ERR_CAPACITY && cap < (1 << 22)) { cap *= 4; continue; }
+      if (rc != HC_OK) {
+        objects.clear();
+        throw std::runtime_error(std::string("hip_cascade::detectMultiScale: ") + hc_last_error());
+      }
+      objects.resize(n);
+      return;
+    }
+  }
+
+ private:
+  hc_cascade* h_ = nullptr;
+};
+
+}  // namespace hip_cascade
