@@ -195,8 +195,22 @@ def main():
             per_launch = {k: v / args.steps for k, v in kernel_ms.items()}
             dom = max(per_launch, key=per_launch.get)
             achieved = alg_bytes * B / (per_launch[dom] * 1e-3) / 1e9
+            # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+            # command (tools/prof_round.sh -> tools/traffic_from_pmc.py); PMC cannot be collected from
+            # inside this process, so the figure is read from profiles/ and is null when absent/stale.
+            traffic, traffic_src = None, None
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if tf and B == 64 and args.kind == "planted" and args.cascade == "alt":
+                try:
+                    tj = json.load(open(tf[-1]))
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(tf[-1], ROOT)
+                except Exception:
+                    traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                               "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg_bytes * B,
                                "launch_ms": round(per_launch[dom], 4),
                                "all_kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()}}
