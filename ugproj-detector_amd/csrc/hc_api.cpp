@@ -127,6 +127,8 @@ struct hc_context {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipStream_t copy_stream = nullptr;   // D2H of results: never queues behind a later batch on `stream`
+  hipEvent_t ev_done = nullptr;        // recorded on `stream` after the last kernel of a batch
 
   hc::Plan plan;
   bool configured = false;
@@ -343,7 +345,11 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
   }
-  HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+  // results travel on the side stream, ordered after this batch only (not after whatever the
+  // caller enqueues next on `stream`, e.g. the next batch of a software pipeline)
+  HIPCHK(hipEventRecord(c->ev_done, s));
+  HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done, 0));
+  HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->copy_stream));
   c->pending = nframes;
   return HC_OK;
 }
@@ -435,6 +441,11 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   for (auto& e : ctx->ev) {
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
+  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
+    hc_context_destroy(ctx);
+    return set_err(HC_ERR_HIP, "cannot create the result stream / event");
+  }
   if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knobs
   if (const char* e_ = getenv("HC_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
@@ -455,6 +466,8 @@ void hc_context_destroy(hc_context* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   ctx->free_workspace();
   void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -541,7 +554,7 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
   HIPCHK(hipSetDevice(ctx->device));
   const int nframes = ctx->pending;
   ctx->pending = 0;
-  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->copy_stream));     // this batch's kernels + count copy are done
   if (ctx->timed_last && !ctx->plan.levels.empty())
     for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   unsigned int count = *ctx->h_count;
@@ -553,8 +566,8 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
   if (count > cap) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; raise cand_capacity");
   if (count) {
     HIPCHK(hipMemcpyAsync(ctx->h_cand, ctx->d_cand, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                          ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+                          ctx->copy_stream));
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
   }
   // canonical single-thread order: frame -> scale -> y -> x  == ascending key
   std::sort(ctx->h_cand, ctx->h_cand + count);
