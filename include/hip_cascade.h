@@ -140,7 +140,10 @@ HC_API int hc_context_enable_stage_taps(hc_context* ctx, int enable);
 HC_API int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* dst, size_t dst_bytes);
 
 /* ---- profiling: per-kernel device time of the last waited batch (HIP events) ----------- */
-#define HC_NKERNELS 5   /* resize, integral_rows, integral_cols, variance, cascade */
+/* Slots: 0 k_pyramid_integral (fused exact resize + 2-D integral; in the unfused debug mode
+ * HC_FUSED_PREP=0 this slot times k_resize), 1 k_integral_rows and 2 k_integral_cols (0 ms when
+ * fused), 3 k_variance, 4 k_cascade (all cascade launches of the batch). */
+#define HC_NKERNELS 5
 HC_API int hc_context_enable_timing(hc_context* ctx, int enable);
 HC_API int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]);
 HC_API const char* hc_kernel_name(int i);

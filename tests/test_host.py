@@ -26,7 +26,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert "std::" not in code and "torch" not in code and "at::" not in code and "class " not in code
     assert pkg.lib.hc_version().decode().startswith("hip_cascade")
     assert [pkg.lib.hc_kernel_name(i).decode() for i in range(pkg.HC_NKERNELS)] == [
-        "k_resize", "k_integral_rows", "k_integral_cols", "k_variance", "k_cascade"]
+        "k_pyramid_integral", "k_integral_rows", "k_integral_cols", "k_variance", "k_cascade"]
 
 
 @pytest.mark.parametrize("name", ["alt", "alt2", "alt_tree", "default"])

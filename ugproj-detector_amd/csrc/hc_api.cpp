@@ -40,7 +40,7 @@ int set_err(int code, const std::string& what) { g_err = what; return code; }
       return set_err(HC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
   } while (0)
 
-const char* const kKernelNames[HC_NKERNELS] = {"k_resize", "k_integral_rows", "k_integral_cols", "k_variance",
+const char* const kKernelNames[HC_NKERNELS] = {"k_pyramid_integral", "k_integral_rows", "k_integral_cols", "k_variance",
                                                "k_cascade"};
 
 template <class T>
@@ -139,6 +139,7 @@ struct hc_context {
   size_t lds_bytes[2] = {0, 0};
   int tile_words[2] = {0, 0};
   int sparse_max = 32;
+  bool fused_prep = true;   // k_pyramid_integral instead of k_resize + k_integral_rows + k_integral_cols
   int row_stages = 1;
 
   // device
@@ -343,17 +344,28 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (c->taps_enabled) HIPCHK(hipMemsetAsync(c->d_taps, 0xFE, grid_stride * nframes, s));
     int e;
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
-    if ((e = hc::launch_resize(s, nframes, (int)P.resize_items.size(), d_frames, frame_stride, row_step, P.rows,
-                               P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_resize_items, c->d_pyr, pyr_stride)))
-      return set_err(HC_ERR_HIP, std::string("k_resize launch: ") + hipGetErrorString((hipError_t)e));
-    if (timed) HIPCHK(hipEventRecord(c->ev[1], s));
-    if ((e = hc::launch_integral_rows(s, nframes, (int)P.row_items.size(), c->d_pyr, pyr_stride, c->d_levels,
-                                      c->d_row_items, c->d_sum, c->d_sq, int_stride)))
-      return set_err(HC_ERR_HIP, std::string("k_integral_rows launch: ") + hipGetErrorString((hipError_t)e));
-    if (timed) HIPCHK(hipEventRecord(c->ev[2], s));
-    if ((e = hc::launch_integral_cols(s, nframes, (int)P.col_items.size(), c->d_levels, c->d_col_items, c->d_sum,
-                                      c->d_sq, int_stride)))
-      return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
+    if (c->fused_prep) {
+      int max_w = 0;
+      for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
+      // the pyramid bytes only exist as a debug tap in this mode
+      if ((e = hc::launch_pyramid_integral(s, nframes, (int)P.levels.size(), max_w, d_frames, frame_stride, row_step,
+                                           P.rows, P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq,
+                                           int_stride, c->taps_enabled ? c->d_pyr : nullptr, pyr_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_pyramid_integral launch: ") + hipGetErrorString((hipError_t)e));
+      if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
+    } else {
+      if ((e = hc::launch_resize(s, nframes, (int)P.resize_items.size(), d_frames, frame_stride, row_step, P.rows,
+                                 P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_resize_items, c->d_pyr, pyr_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_resize launch: ") + hipGetErrorString((hipError_t)e));
+      if (timed) HIPCHK(hipEventRecord(c->ev[1], s));
+      if ((e = hc::launch_integral_rows(s, nframes, (int)P.row_items.size(), c->d_pyr, pyr_stride, c->d_levels,
+                                        c->d_row_items, c->d_sum, c->d_sq, int_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_integral_rows launch: ") + hipGetErrorString((hipError_t)e));
+      if (timed) HIPCHK(hipEventRecord(c->ev[2], s));
+      if ((e = hc::launch_integral_cols(s, nframes, (int)P.col_items.size(), c->d_levels, c->d_col_items, c->d_sum,
+                                        c->d_sq, int_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
+    }
     if (timed) HIPCHK(hipEventRecord(c->ev[3], s));
     if ((e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
@@ -490,6 +502,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
   if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
   if (const char* e_ = getenv("HC_PAIR")) ctx->pair_mode = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0;
   if (ctx->pair_mode && !getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = 16;
   if (ctx->pair_mode && ctx->band_rows[0] == 32) ctx->band_rows[0] = 16;
   for (int k = 0; k < 2; k++)

@@ -38,6 +38,11 @@ struct CascadeArgs {
 int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames, size_t frame_stride,
                   size_t row_step, int rows, int cols, const DevLevel* levels, const uint32_t* xtab,
                   const uint32_t* ytab, const WorkItem* items, uint8_t* pyr, size_t pyr_stride);
+// fused resize + row scan + column scan: one workgroup per (level, frame); pyr may be null
+int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
+                            size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
+                            const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
+                            uint8_t* pyr, size_t pyr_stride);
 int launch_integral_rows(hipStream_t st, int nframes, int nitems, const uint8_t* pyr, size_t pyr_stride,
                          const DevLevel* levels, const WorkItem* items, uint32_t* sum, uint32_t* sq,
                          size_t int_stride);

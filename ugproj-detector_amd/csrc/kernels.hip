@@ -36,6 +36,20 @@ __device__ __forceinline__ WorkItem load_item(const WorkItem* items, int i) {
   return w;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with DPP (no LDS traffic, no bpermute
+// latency): Hillis-Steele inside each row of 16 lanes (row_shr 1/2/4/8, out-of-row lanes read 0),
+// then row_bcast:15 carries row totals into rows 1 and 3, row_bcast:31 carries the half-wave
+// total into rows 2 and 3.  u32 modular, exact.
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1,3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------
 // A.4  pyramid: dst(level, dy, dx) from the ORIGINAL frame, 8.8 x 8.8 fixed point
 // block = 64 x 4 destination pixels
@@ -63,7 +77,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_resize(
 }
 
 // ------------------------------------------------------------------------------------------
-// A.5 pass 1: one wavefront per pyramid row; inclusive scan over 64 lanes by __shfl_up,
+// A.5 pass 1: one wavefront per pyramid row; inclusive scan over 64 lanes by DPP (wave_scan_u32),
 // carry in a register across 64-pixel chunks.  Writes I[y+1][x+1] = sum_{j<=x} p[y][j].
 __global__ __launch_bounds__(WG_THREADS) void k_integral_rows(
     const uint8_t* __restrict__ pyr, size_t pyr_stride, const DevLevel* __restrict__ levels,
@@ -83,17 +97,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_rows(
   for (int x0 = 0; x0 < w; x0 += 64) {
     const int x = x0 + lane;
     const uint32_t p = x < w ? src[x] : 0u;
-    uint32_t s = p, q = p * p;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t ts = __shfl_up(s, d, 64), tq = __shfl_up(q, d, 64);
-      if (lane >= d) { s += ts; q += tq; }
-    }
-    s += carry_s;
-    q += carry_q;
+    const uint32_t s = wave_scan_u32(p) + carry_s;
+    const uint32_t q = wave_scan_u32(p * p) + carry_q;
     if (x < w) { S[x] = s; Q[x] = q; }
-    carry_s = __shfl(s, 63, 64);
-    carry_q = __shfl(q, 63, 64);
+    carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+    carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
   }
 }
 
@@ -126,6 +134,99 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_cols(
   for (; y < h; y++) {
     as += S[(size_t)y * pitch]; aq += Q[(size_t)y * pitch];
     S[(size_t)y * pitch] = as; Q[(size_t)y * pitch] = aq;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// A.4 + A.5 fused: one workgroup owns one pyramid level of one frame and marches down it in chunks
+// of R rows.  Phase 1 (wave per row): exact-bilinear pixels straight from the original frame
+// (L2-resident), 64-lane DPP inclusive scan of p and p*p with a register carry along the
+// row -> row prefixes in LDS.  Phase 2 (thread per column): running column sums kept in
+// registers across chunks, final integral rows stored coalesced.  The pyramid never touches
+// HBM (unless the debug tap asks for it) and `sum`/`sqsum` are written exactly once:
+// HBM traffic = the algorithmic 8 B per integral element.
+constexpr int PI_THREADS = 512;   // 8 wavefronts: one pyramid row each per chunk of 8 rows
+constexpr int PI_UNROLL = 4;      // 64-pixel chunks whose source loads are in flight together
+
+template <int CMAX>   // columns per thread: level width <= PI_THREADS * CMAX
+__global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
+    const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_step, int rows, int cols,
+    const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
+    uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
+    size_t pyr_stride, int R, int lds_pitch) {
+  extern __shared__ uint32_t rowbuf[];                 // [2][R][lds_pitch] row prefixes | [lds_pitch] x table
+  uint32_t* rs = rowbuf;
+  uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
+  uint32_t* xt_s = rowbuf + (size_t)2 * R * lds_pitch;
+  const HC_CONST DevLevel& L = as_const(levels)[blockIdx.y];
+  const int frame = blockIdx.x;
+  const int w = L.w, h = L.h, pitch = L.int_pitch;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint8_t* src = frames + (size_t)frame * frame_stride;
+  const uint32_t* yt_l = ytab + L.ytab_ofs;
+  uint32_t* S = sum + (size_t)frame * int_stride + L.int_ofs;
+  uint32_t* Q = sq + (size_t)frame * int_stride + L.int_ofs;
+  uint8_t* P = pyr ? pyr + (size_t)frame * pyr_stride + L.pyr_ofs : nullptr;
+  uint32_t col_s[CMAX], col_q[CMAX];
+#pragma unroll
+  for (int k = 0; k < CMAX; k++) col_s[k] = col_q[k] = 0;
+  for (int x = threadIdx.x; x < lds_pitch; x += PI_THREADS) xt_s[x] = x < w ? xtab[L.xtab_ofs + x] : 0u;
+  __syncthreads();
+
+  for (int y0 = 0; y0 < h; y0 += R) {
+    const int nr = min(R, h - y0);
+    for (int r = wave; r < nr; r += PI_THREADS / 64) {
+      const int dy = y0 + r;
+      const uint32_t yt = yt_l[dy];
+      const int oy = yt >> 9, oy1 = min(oy + 1, rows - 1);
+      const uint32_t cy1 = yt & 511u, cy0 = 256u - cy1;
+      const uint8_t* r0 = src + (size_t)oy * row_step;
+      const uint8_t* r1 = src + (size_t)oy1 * row_step;
+      uint32_t carry_s = 0, carry_q = 0;
+      for (int x0 = 0; x0 < w; x0 += 64 * PI_UNROLL) {
+        // all source bytes of PI_UNROLL chunks are requested before the first scan consumes any
+        uint32_t px[PI_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PI_UNROLL; u++) {
+          const int x = x0 + 64 * u + lane;
+          const uint32_t xt = xt_s[min(x, lds_pitch - 1)];
+          const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
+          const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
+          const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
+          const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+          px[u] = x < w ? min((h0 * cy0 + h1 * cy1 + 32768u) >> 16, 255u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PI_UNROLL; u++) {
+          const int x = x0 + 64 * u + lane;
+          if (x0 + 64 * u >= w) break;                   // wave-uniform
+          if (P && x < w) P[(size_t)dy * w + x] = (uint8_t)px[u];
+          const uint32_t s = wave_scan_u32(px[u]) + carry_s;
+          const uint32_t q = wave_scan_u32(px[u] * px[u]) + carry_q;
+          if (x < w) { rs[r * lds_pitch + x] = s; rq[r * lds_pitch + x] = q; }
+          carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+          carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CMAX; k++) {
+      const int x = threadIdx.x + k * PI_THREADS;
+      if (x < w) {
+        uint32_t cs = col_s[k], cq = col_q[k];
+        uint32_t* so = S + (size_t)(y0 + 1) * pitch + x + 1;
+        uint32_t* qo = Q + (size_t)(y0 + 1) * pitch + x + 1;
+        for (int r = 0; r < nr; r++) {
+          cs += rs[r * lds_pitch + x];
+          cq += rq[r * lds_pitch + x];
+          so[(size_t)r * pitch] = cs;
+          qo[(size_t)r * pitch] = cq;
+        }
+        col_s[k] = cs; col_q[k] = cq;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -710,6 +811,28 @@ int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames
   if (nitems == 0 || nframes == 0) return 0;
   hipLaunchKernelGGL(k_resize, dim3(nitems, nframes), dim3(WG_THREADS), 0, st, frames, frame_stride, row_step,
                      rows, cols, levels, xtab, ytab, items, pyr, pyr_stride);
+  HC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
+                            size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
+                            const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
+                            uint8_t* pyr, size_t pyr_stride) {
+  if (nlevels == 0 || nframes == 0) return 0;
+  const int lds_pitch = (max_w + 63) & ~63;
+  int R = 8;                                     // rows per chunk: (2 R + 1) x pitch words of LDS, <= 64 KB
+  while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 > 65536) R >>= 1;
+  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4;
+  const dim3 grid(nframes, nlevels), block(PI_THREADS);
+#define HC_PI(C)                                                                                                  \
+  hipLaunchKernelGGL((k_pyramid_integral<C>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
+                     levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch)
+  if (max_w <= 2 * PI_THREADS) HC_PI(2);
+  else if (max_w <= 4 * PI_THREADS) HC_PI(4);
+  else if (max_w <= 8 * PI_THREADS) HC_PI(8);
+  else return (int)hipErrorInvalidValue;
+#undef HC_PI
   HC_LAUNCH_CHECK();
   return 0;
 }
