@@ -155,12 +155,6 @@ struct hc_context {
   hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
                *d_band_items[2] = {nullptr, nullptr};
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
-  // two-windows-per-lane kernel for the ystep-1 levels (k_cascade_pair)
-  bool pair_mode = false;   // opt-in (HC_PAIR=1): bit-exact but slower than k_cascade on MI355X
-  hc::TileGeom geom_pair{};
-  size_t lds_pair = 0;
-  int tile_words_pair = 0;
-  hc::DevNode *d_nodes_pair = nullptr, *d_nodes_pair_single = nullptr;
   hc::DevStage* d_stages = nullptr;
   hc::DevTree* d_trees = nullptr;
   float* d_leaves = nullptr;
@@ -279,31 +273,6 @@ int upload_model(hc_context* c) {
     c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 16;
     build_nodes(m, c->geom[k], ystep, nd[k]);
   }
-  if (c->pair_mode) {
-    // tile of 128 positions x band_rows[0] rows, kept twice (A and B = A shifted by one word)
-    hc::TileGeom g{};
-    g.cols = 2 * hc::TILE_POS - 1 + m.win_w + 1;
-    g.pitch = (g.cols + 1) & ~1;                      // even: every row starts 8-byte aligned
-    g.half = 0;
-    g.rows = c->band_rows[0] - 1 + m.win_h + 1;
-    const int words = g.pitch * g.rows;               // even
-    if (2 * (size_t)words > 2 * 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for the pair tile");
-    c->geom_pair = g;
-    c->tile_words_pair = words;
-    c->lds_pair = (size_t)words * 8 + (size_t)c->band_rows[0] * 64 * 2 * 2 + 16;
-    std::vector<hc::DevNode> np, ns;
-    build_nodes(m, g, 1, ns);                          // single-window word offsets in copy A
-    np = ns;
-    for (hc::DevNode& d : np)
-      for (int k = 0; k < 12; k++) {
-        const int idx = d.off[k];
-        const int word = (idx & 1) ? words + idx - 1 : idx;   // odd corners read the shifted copy
-        d.off[k] = (uint16_t)(word >> 1);               // uint2 index
-      }
-    int rc2;
-    if ((rc2 = dev_upload(&c->d_nodes_pair, np))) return rc2;
-    if ((rc2 = dev_upload(&c->d_nodes_pair_single, ns))) return rc2;
-  }
   std::vector<hc::DevStage> st;
   std::vector<hc::DevTree> tr;
   for (const hc::ModelStage& s : m.stages) {
@@ -383,14 +352,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.cand = c->d_cand; A.cand_count = c->d_count;
       A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
-      if (k == 0 && c->pair_mode) {
-        A.nodes = c->d_nodes_pair; A.nodes_single = c->d_nodes_pair_single;
-        A.g = c->geom_pair; A.tile_words = c->tile_words_pair;
-        A.sparse_max = c->sparse_max / 2;               // counted in window pairs
-        e = hc::launch_cascade_pair(s, nframes, !m.is_stump(), c->band_rows[0], c->lds_pair, A);
-      } else {
-        e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->lds_bytes[k], A);
-      }
+      e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
@@ -501,10 +463,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
   if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
-  if (const char* e_ = getenv("HC_PAIR")) ctx->pair_mode = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0;
-  if (ctx->pair_mode && !getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = 16;
-  if (ctx->pair_mode && ctx->band_rows[0] == 32) ctx->band_rows[0] = 16;
   for (int k = 0; k < 2; k++)
     if (ctx->band_rows[k] != 8 && ctx->band_rows[k] != 16 && ctx->band_rows[k] != 32) {
       delete ctx;
@@ -523,8 +482,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   ctx->free_workspace();
-  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_nodes_pair,
-                  ctx->d_nodes_pair_single};
+  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -18,8 +18,7 @@ struct CascadeArgs {
   const DevLevel* levels;
   const WorkItem* bands;      // bands of ONE ystep class (all share geometry g)
   int nbands;
-  const DevNode* nodes;       // corner offsets resolved for g (k_cascade_pair: uint2 indices into [A | B])
-  const DevNode* nodes_single; // k_cascade_pair only: single-window word offsets in copy A (sparse mode)
+  const DevNode* nodes;       // corner offsets resolved for g
   const DevStage* stages;
   int nstages;
   const DevTree* trees;
@@ -53,7 +52,5 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
                     float* vnf, size_t grid_stride);
 // rows = band height in grid rows (8, 16 or 32); lds_bytes = tile + 2 queues + counters
 int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args);
-// ystep-1 levels, two windows per lane (rows 8 or 16); lds_bytes = 2 tile copies + 2 queues + counters
-int launch_cascade_pair(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args);
 
 }  // namespace hc

@@ -483,7 +483,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
       if (sm) {
         int off = 0;
         if (lane == 0) off = atomicAdd(&cnt[0], __popcll(sm));
-        off = __shfl(off, 0, 64);
+        off = __builtin_amdgcn_readfirstlane(off);
         if (surv) queue[off + __popcll(sm & lt_mask)] = (uint16_t)(rr * TILE_POS + lane);
       }
     }
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
           if (sm) {
             int off = 0;
             if (lane == 0) off = atomicAdd(cout, __popcll(sm));
-            off = __shfl(off, 0, 64);
+            off = __builtin_amdgcn_readfirstlane(off);
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
           if (A.taps && active && !ok) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
@@ -548,254 +548,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
         const unsigned int slot = atomicAdd(A.cand_count, 1u);
         if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
         if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_cascade_pair: the ystep-1 levels with TWO horizontally adjacent windows per lane.
-//
-// The cascade kernel is bound by LDS bandwidth (ds_read_b32 moves 128 B/clk/CU, ds_read_b64 256).
-// Windows x and x+1 need, for every rect corner, two adjacent integral words -> one 8-byte LDS
-// read serves both, provided it is 8-byte aligned.  Lane l owns positions 2l and 2l+1 of a row, so
-// the pair starts at an even word exactly for corners with even dy*pitch+dx; for the odd ones the
-// tile is kept a second time shifted by one word (copy B[j] = A[j+1]).  The host resolves every
-// corner to "uint2 index in [A | B]" (DevNode::off holds word_offset/2), so the device code is one
-// ds_read_b64 per corner and per window pair.  Same arithmetic per window as k_cascade.
-__device__ __forceinline__ void feature_value_pair(const uint2* tile2, int base2, const NodeRegs& n, float vnfa,
-                                                   float vnfb, float& fa, float& fb) {
-  const uint2 c0 = tile2[base2 + HC_OFF(n.q0, 0)], c1 = tile2[base2 + HC_OFF(n.q0, 1)],
-              c2 = tile2[base2 + HC_OFF(n.q0, 2)], c3 = tile2[base2 + HC_OFF(n.q0, 3)];
-  const uint2 d0 = tile2[base2 + HC_OFF(n.q0, 4)], d1 = tile2[base2 + HC_OFF(n.q0, 5)],
-              d2 = tile2[base2 + HC_OFF(n.q0, 6)], d3 = tile2[base2 + HC_OFF(n.q0, 7)];
-  const int s0a = (int)(c0.x - c1.x - c2.x + c3.x), s0b = (int)(c0.y - c1.y - c2.y + c3.y);
-  const int s1a = (int)(d0.x - d1.x - d2.x + d3.x), s1b = (int)(d0.y - d1.y - d2.y + d3.y);
-  const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]), w2 = __uint_as_float(n.q2[0]);
-  float ra = w0 * (float)s0a + w1 * (float)s1a;
-  float rb = w0 * (float)s0b + w1 * (float)s1b;
-  if (w2 != 0.0f) {   // wave-uniform branch
-    const uint2 e0 = tile2[base2 + HC_OFF(n.q1, 0)], e1 = tile2[base2 + HC_OFF(n.q1, 1)],
-                e2 = tile2[base2 + HC_OFF(n.q1, 2)], e3 = tile2[base2 + HC_OFF(n.q1, 3)];
-    ra += w2 * (float)(int)(e0.x - e1.x - e2.x + e3.x);
-    rb += w2 * (float)(int)(e0.y - e1.y - e2.y + e3.y);
-  }
-  fa = ra * vnfa;
-  fb = rb * vnfb;
-}
-
-template <bool TREE>
-__device__ __forceinline__ void stage_passes_pair(const uint2* tile2, int base2, float vnfa, float vnfb,
-                                                  const HC_CONST DevStage& st, const HC_CONST DevNode* nodes,
-                                                  const HC_CONST DevTree* trees, const float* __restrict__ leaves,
-                                                  bool& oka, bool& okb) {
-  double acca = 0.0, accb = 0.0;
-  const int first = st.first, count = st.count;
-  const float sthr = st.thr;
-  if (!TREE) {
-    NodeRegs cur = load_node(nodes, first);
-    for (int t = 0; t < count; t++) {
-      const NodeRegs nxt = load_node(nodes, first + min(t + 1, count - 1));
-      float va, vb;
-      feature_value_pair(tile2, base2, cur, vnfa, vnfb, va, vb);
-      const float thr = __uint_as_float(cur.q2[1]), l = __uint_as_float(cur.q2[2]), r = __uint_as_float(cur.q2[3]);
-      acca += (double)(va < thr ? l : r);
-      accb += (double)(vb < thr ? l : r);
-      cur = nxt;
-    }
-  } else {
-    for (int t = 0; t < count; t++) {
-      const HC_CONST DevTree& T = trees[first + t];
-      const int fn = T.first_node, nn = T.nnodes, fl = T.first_leaf;
-      int ata = 0, atb = 0;
-      NodeRegs cur = load_node(nodes, fn);
-      for (int k = 0; k < nn; k++) {
-        const NodeRegs nxt = load_node(nodes, fn + min(k + 1, nn - 1));
-        float va, vb;
-        feature_value_pair(tile2, base2, cur, vnfa, vnfb, va, vb);
-        const float thr = __uint_as_float(cur.q2[1]);
-        const int goa = va < thr ? (int)cur.q2[2] : (int)cur.q2[3];
-        const int gob = vb < thr ? (int)cur.q2[2] : (int)cur.q2[3];
-        ata = (ata == k) ? goa : ata;
-        atb = (atb == k) ? gob : atb;
-        cur = nxt;
-      }
-      acca += (double)leaves[fl - ata];
-      accb += (double)leaves[fl - atb];
-    }
-  }
-  oka = !(acca < (double)sthr);
-  okb = !(accb < (double)sthr);
-}
-
-// LDS layout: [ A: tile_words ][ B: tile_words ][ 2 queues: ROWS*64 x u16 ][ 3 counters ]
-// queue entry = pair id (row*64 + lane, 11 bits) | alive mask << 12 (bit 0: window 2l, bit 1: 2l+1)
-template <bool TREE, int ROWS>
-__global__ __launch_bounds__(WG_THREADS) void k_cascade_pair(CascadeArgs A) {
-  constexpr int TILE_PAIRS = ROWS * 64;
-  constexpr int NW = WG_THREADS / 64;
-  constexpr int STEP = 2 * TILE_POS;                           // 128 positions per tile step
-  extern __shared__ int32_t smem[];
-  int32_t* tileA = smem;
-  int32_t* tileB = smem + A.tile_words;
-  const uint2* tile2 = (const uint2*)smem;
-  uint16_t* queue = (uint16_t*)(smem + 2 * A.tile_words);
-  int* cnt = (int*)(queue + 2 * TILE_PAIRS);
-  const int band = blockIdx.y;
-  const WorkItem it = load_item(A.bands, band);
-  const HC_CONST DevLevel& L = as_const(A.levels)[it.level];
-  const HC_CONST DevStage* stages = as_const(A.stages);
-  const HC_CONST DevTree* trees = as_const(A.trees);
-  const HC_CONST DevNode* nodes = as_const(A.nodes);           // pair geometry (uint2 indices)
-  const int frame = blockIdx.x;
-  const TileGeom G = A.g;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int gy0 = it.a;
-  const int nx = L.nx, ny = L.ny;
-  const uint32_t* __restrict__ I = A.sum + (size_t)frame * A.int_stride + L.int_ofs;
-  const size_t grid_base = (size_t)frame * A.grid_stride + L.grid_ofs;
-  const float* __restrict__ vnf_g = A.vnf + grid_base;
-  const unsigned long long key_hi = ((unsigned long long)frame << 40) | ((unsigned long long)it.level << 32);
-  const unsigned long long lt_mask = lane ? ((1ull << lane) - 1ull) : 0ull;
-  const unsigned long long le_mask = lt_mask | (1ull << lane);
-  unsigned int carry = 0xffffffffu;
-
-  for (int gx0 = 0; gx0 < nx; gx0 += STEP) {
-    __syncthreads();
-    for (int r = wave; r < G.rows; r += NW) {
-      const int sy = gy0 + r;
-      const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
-      int32_t* da = tileA + r * G.pitch;
-      int32_t* db = tileB + r * G.pitch - 1;
-      for (int c = lane; c < G.cols; c += 64) {
-        const int sx = gx0 + c;
-        const int32_t v = (sy <= L.h && sx <= L.w) ? (int32_t)srow[sx] : 0;
-        da[c] = v;
-        if (c) db[c] = v;                                         // B[j] = A[j + 1]
-      }
-    }
-    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
-    __syncthreads();
-
-    // ---- stage 0 on all 128 x ROWS positions; x-skip chain over a0 b0 a1 b1 ..; pairs -> queue 0
-#pragma unroll
-    for (int j = 0; j < ROWS / NW; j++) {
-      const int rr = wave + NW * j;
-      const int gy = gy0 + rr;
-      if (gy >= ny) continue;                                     // wave-uniform
-      const int gxa = gx0 + 2 * lane, gxb = gxa + 1;
-      const bool valid_a = gxa < nx, valid_b = gxb < nx;
-      const float vnfa = valid_a ? vnf_g[(size_t)gy * nx + gxa] : 0.f;
-      const float vnfb = valid_b ? vnf_g[(size_t)gy * nx + gxb] : 0.f;
-      const bool ev_a = vnfa > 0.f, ev_b = vnfb > 0.f;
-      const int base2 = (rr * G.pitch) / 2 + lane;                // pitch is even
-      bool p0a, p0b;
-      stage_passes_pair<TREE>(tile2, base2, vnfa, vnfb, stages[0], nodes, trees, A.leaves, p0a, p0b);
-      const bool fa = ev_a && !p0a, fb = ev_b && !p0b;
-      // A.7 closed form over positions 2l (a) and 2l+1 (b): nearest position below with f == 0
-      const unsigned long long fma = __ballot(fa), fmb = __ballot(fb);
-      const unsigned long long zb = ~fmb & lt_mask;               // b-positions 2j+1, j < l
-      const unsigned long long za_a = ~fma & lt_mask;             // a-positions 2j, j < l   (below 2l)
-      const unsigned long long za_b = ~fma & le_mask;             // a-positions 2j, j <= l  (below 2l+1)
-      const int top_b = zb ? 2 * (63 - __clzll((long long)zb)) + 1 : -1;
-      const int top_aa = za_a ? 2 * (63 - __clzll((long long)za_a)) : -1;
-      const int top_ab = za_b ? 2 * (63 - __clzll((long long)za_b)) : -1;
-      const int first_anchor = ((carry >> j) & 1u) ? 0 : 1;
-      const int ta = max(top_aa, top_b), tb = max(top_ab, top_b);
-      const int anchor_a = ta >= 0 ? ta + 1 : first_anchor;
-      const int anchor_b = tb >= 0 ? tb + 1 : first_anchor;
-      const bool vis_a = ((2 * lane - anchor_a) & 1) == 0;
-      const bool vis_b = ((2 * lane + 1 - anchor_b) & 1) == 0;
-      const unsigned long long vmb = __ballot(vis_b);
-      if (((vmb & fmb) >> 63) & 1ull) carry &= ~(1u << j); else carry |= (1u << j);
-
-      const bool sa = valid_a && vis_a && ev_a && p0a, sb = valid_b && vis_b && ev_b && p0b;
-      if (A.taps) {
-        if (valid_a && vis_a && !sa) A.taps[grid_base + (size_t)gy * nx + gxa] = (int8_t)(ev_a ? 0 : -1);
-        if (valid_b && vis_b && !sb) A.taps[grid_base + (size_t)gy * nx + gxb] = (int8_t)(ev_b ? 0 : -1);
-      }
-      const bool any = sa || sb;
-      const unsigned long long sm = __ballot(any);
-      if (sm) {
-        int off = 0;
-        if (lane == 0) off = atomicAdd(&cnt[0], __popcll(sm));
-        off = __shfl(off, 0, 64);
-        if (any) queue[off + __popcll(sm & lt_mask)] = (uint16_t)((rr * 64 + lane) | ((sa ? 1 : 0) << 12) | ((sb ? 2 : 0) << 12));
-      }
-    }
-    __syncthreads();
-
-    int s = 1;
-    for (; s < A.nstages; s++) {
-      const int t = s - 1;
-      const int n = cnt[t % 3];
-      if (n == 0) break;
-      const uint16_t* qin = queue + (t & 1) * TILE_PAIRS;
-      uint16_t* qout = queue + ((t + 1) & 1) * TILE_PAIRS;
-      int* cout = &cnt[(t + 1) % 3];
-      if (threadIdx.x == 0) cnt[(t + 2) % 3] = 0;
-      if (n <= A.sparse_max && stages[s].exact) {
-        // few pairs: one window per wavefront (single-window reads from copy A), lanes across weak classifiers
-        const int sfirst = stages[s].first, scount = stages[s].count;
-        const float sthr = stages[s].thr;
-        for (int i = wave; i < n; i += NW) {
-          const int e = qin[i];
-          const int pr = e & 0xfff, m = e >> 12;
-          const int wy = gy0 + (pr >> 6), wx = gx0 + 2 * (pr & 63);
-          int m2 = 0;
-          for (int b = 0; b < 2; b++) {
-            if (!((m >> b) & 1)) continue;                        // wave-uniform
-            const int base = (pr >> 6) * G.pitch + 2 * (pr & 63) + b;
-            const bool ok = stage_passes_sparse<TREE>(tileA, base, vnf_g[(size_t)wy * nx + wx + b], sfirst, scount, sthr,
-                                                      lane, A.nodes_single, A.trees, A.leaves);
-            if (ok) m2 |= 1 << b;
-            else if (A.taps && lane == 0) A.taps[grid_base + (size_t)wy * nx + wx + b] = (int8_t)s;
-          }
-          if (lane == 0 && m2) qout[atomicAdd(cout, 1)] = (uint16_t)(pr | (m2 << 12));
-        }
-      } else {
-        for (int i0 = wave * 64; i0 < n; i0 += WG_THREADS) {
-          const int i = i0 + lane;
-          const bool active = i < n;
-          const int e = active ? qin[i] : qin[0];
-          const int pr = e & 0xfff, m = active ? (e >> 12) : 0;
-          const int wy = gy0 + (pr >> 6), wx = gx0 + 2 * (pr & 63);
-          const int base2 = ((pr >> 6) * G.pitch) / 2 + (pr & 63);
-          const float vnfa = vnf_g[(size_t)wy * nx + wx], vnfb = vnf_g[(size_t)wy * nx + wx + 1];
-          bool oka, okb;
-          stage_passes_pair<TREE>(tile2, base2, vnfa, vnfb, stages[s], nodes, trees, A.leaves, oka, okb);
-          const int m2 = m & ((oka ? 1 : 0) | (okb ? 2 : 0));
-          const unsigned long long sm = __ballot(m2 != 0);
-          if (sm) {
-            int off = 0;
-            if (lane == 0) off = atomicAdd(cout, __popcll(sm));
-            off = __shfl(off, 0, 64);
-            if (m2) qout[off + __popcll(sm & lt_mask)] = (uint16_t)(pr | (m2 << 12));
-          }
-          if (A.taps) {
-            const int died = m & ~m2;
-            if (died & 1) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
-            if (died & 2) A.taps[grid_base + (size_t)wy * nx + wx + 1] = (int8_t)s;
-          }
-        }
-      }
-      __syncthreads();
-    }
-    if (s == A.nstages) {
-      const int t = s - 1;
-      const int n = cnt[t % 3];
-      const uint16_t* qin = queue + (t & 1) * TILE_PAIRS;
-      for (int i = threadIdx.x; i < n; i += WG_THREADS) {
-        const int e = qin[i];
-        const int pr = e & 0xfff, m = e >> 12;
-        const int gy = gy0 + (pr >> 6);
-        for (int b = 0; b < 2; b++) {
-          if (!((m >> b) & 1)) continue;
-          const int gx = gx0 + 2 * (pr & 63) + b;
-          const unsigned int slot = atomicAdd(A.cand_count, 1u);
-          if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
-          if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
-        }
       }
     }
   }
@@ -883,24 +635,6 @@ int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_
   if (args.nbands == 0 || nframes == 0) return 0;
   return tree ? launch_cascade_rows<true>(st, nframes, rows, lds_bytes, args)
               : launch_cascade_rows<false>(st, nframes, rows, lds_bytes, args);
-}
-
-template <bool TREE>
-static int launch_cascade_pair_rows(hipStream_t st, int nframes, int rows, size_t lds_bytes, const CascadeArgs& args) {
-  const dim3 grid(nframes, args.nbands), block(WG_THREADS);
-  switch (rows) {
-    case 8: hipLaunchKernelGGL((k_cascade_pair<TREE, 8>), grid, block, lds_bytes, st, args); break;
-    case 16: hipLaunchKernelGGL((k_cascade_pair<TREE, 16>), grid, block, lds_bytes, st, args); break;
-    default: return (int)hipErrorInvalidValue;
-  }
-  HC_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_cascade_pair(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args) {
-  if (args.nbands == 0 || nframes == 0) return 0;
-  return tree ? launch_cascade_pair_rows<true>(st, nframes, rows, lds_bytes, args)
-              : launch_cascade_pair_rows<false>(st, nframes, rows, lds_bytes, args);
 }
 
 }  // namespace hc
