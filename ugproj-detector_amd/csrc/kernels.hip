@@ -394,8 +394,11 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
 // lane k's corner reads are stride-1 in LDS).  Wave w owns grid rows w, w+4, .. of the band
 // for the whole walk, so the x-skip carry (A.7) stays in its registers.  Bigger ROWS = bigger
 // survivor pool per workgroup = fuller wavefronts in the middle stages, and less halo per window.
+#ifndef HC_CASCADE_WAVES
+#define HC_CASCADE_WAVES 8   // waves per SIMD the register allocator must leave room for
+#endif
 template <bool TREE, int ROWS>
-__global__ __launch_bounds__(WG_THREADS) void k_cascade(CascadeArgs A) {
+__global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(CascadeArgs A) {
   constexpr int TILE_WIN = ROWS * TILE_POS;
   constexpr int NW = WG_THREADS / 64;
   extern __shared__ int32_t smem[];
