@@ -298,3 +298,55 @@ def test_sparse_mode_and_its_ordered_fallback(pkg, oracle, synth, tmp_path, name
     grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
     assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
     assert len(raw) > 0
+
+
+@pytest.mark.parametrize("name", ["alt2", "default"])
+def test_full_size_1080p_two_cascades(pkg, oracle, synth, name):
+    """BASELINE config #3: 1920x1080, alt2 and default (24x24 window) on the same frame."""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frame = synth.planted(1080, 1920, synth.frame_seed(2))[0]
+    ctx = pkg.Context(casc)
+    ctx.configure(1080, 1920, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=1 << 15)
+    assert len(ctx.levels()) == 37
+    assert ctx.algorithmic_bytes() == (76051696 if name == "alt2" else 110293312)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frame[None])
+    grouped, raw, otaps = oc.detect(frame, 1.1, 2, (30, 30), (0, 0), want_taps=True)
+    for li in range(37):
+        assert np.array_equal(ctx.read_tap(0, li, pkg.TAP_STAGES), otaps[li]), li
+    assert np.array_equal(ctx.raw_candidates(1)[0], raw)
+    assert np.array_equal(got[0], grouped) and len(grouped) >= 4
+
+
+def test_full_size_2160p(pkg, oracle, synth):
+    """BASELINE config #5 geometry: one 3840x2160 frame (45 levels, 2384-pixel-wide level 0)."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frame = synth.planted(2160, 3840, synth.frame_seed(3), nfaces=8, min_size=60, max_size=500)[0]
+    ctx = pkg.Context(casc)
+    ctx.configure(2160, 3840, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=1 << 16)
+    assert len(ctx.levels()) == 45 and ctx.algorithmic_bytes() == 303677664
+    got = ctx.detect_host(frame[None])
+    grouped, raw = oc.detect(frame, 1.1, 2, (30, 30), (0, 0))
+    assert np.array_equal(ctx.raw_candidates(1)[0], raw)
+    assert np.array_equal(got[0], grouped) and len(grouped) >= 4
+    # integral of the widest level against the oracle (exercises the widest k_pyramid_integral variant)
+    L = ctx.levels()[0]
+    img = oracle.resize_linear_exact(frame, L.h, L.w)
+    s, q = oracle.integral(img)
+    assert np.array_equal(ctx.read_tap(0, 0, pkg.TAP_SUM), s) and np.array_equal(ctx.read_tap(0, 0, pkg.TAP_SQSUM), q)
+
+
+def test_unfused_prep_kernels_agree(pkg, oracle, synth, monkeypatch):
+    """HC_FUSED_PREP=0 keeps the three-kernel pyramid/integral path alive (debug / A-B): same taps."""
+    monkeypatch.setenv("HC_FUSED_PREP", "0")
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr, _ = synth.planted(240, 320, synth.frame_seed(1), nfaces=3, min_size=40, max_size=110)
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), 1, 1 << 14)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(fr[None])
+    grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
+    assert np.array_equal(got[0], grouped)
