@@ -108,11 +108,19 @@ def main():
     ctx = ctxs[0]
     alg_bytes = ctx.algorithmic_bytes()
 
+    # the RCCL gather of box records runs on its own stream: it must not queue behind the kernels
+    # of the next batch that are already enqueued on the compute stream
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+
     def finish(c, global_step):
         boxes = c.wait(B)
         lo = (global_step * world + rank) * B
         rec = shard.pack_records(range(lo, lo + B), boxes)
-        allrec = shard.gather_records(rec, dev if world > 1 else None)
+        if world > 1:
+            with torch.cuda.stream(comm_stream):
+                allrec = shard.gather_records(rec, dev)
+        else:
+            allrec = shard.gather_records(rec, None)
         return boxes, allrec
 
     def run_steps(nsteps, on_done=None):
