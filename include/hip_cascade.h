@@ -100,6 +100,25 @@ HC_API int  hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity
 /* Raw (ungrouped) candidates of the last waited batch, canonical order (scale,y,x) per frame. */
 HC_API int  hc_batch_raw_candidates(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets);
 
+/* ---- the caller of the path: FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) ----
+ * BGR 8UC3 frame in, skin-filtered face rectangles out.  On device, in the reference's order:
+ * cvtColor(BGR2YCrCb) + inRange(lower, upper) -> mask (:17-18); cvtColor(BGR2GRAY) + equalizeHist +
+ * gray &= mask (:20-22); detectMultiScale(gray, faces, scale, 2, 0|CASCADE_SCALE_IMAGE, Size(30,30))
+ * (:25-31); keep a rect iff norm(mean(mask(roi)))/256 >= 0.8 (:33-42).  lower/upper are the YCrCb
+ * bounds cfg.detection.skin_lower/upper (reference src/structure.cc:75-82).
+ * hc_detect_faces is the synchronous single-frame form (configures minNeighbors 2, minSize 30x30
+ * itself).  The batched form needs a context configured with those values and
+ * hc_context_enable_faces (allocates the BGR/mask workspace once). */
+HC_API int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step_bytes,
+                           const int lower[3], const int upper[3], double scale_factor,
+                           hc_rect* out, int out_capacity, int* out_count);
+HC_API int hc_context_enable_faces(hc_context* ctx);
+HC_API int hc_faces_batch_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride_bytes,
+                                  size_t row_step_bytes, int nframes, const int lower[3], const int upper[3]);
+HC_API int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t frame_stride_bytes,
+                                       size_t row_step_bytes, int nframes, const int lower[3], const int upper[3]);
+HC_API int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets);
+
 /* ---- plan introspection (tests, bench accounting) -------------------------------------- */
 typedef struct hc_level {
   float   scale;
@@ -132,8 +151,10 @@ typedef enum hc_tap {
   HC_TAP_SUM = 1,       /* i32 [(h+1)][(w+1)] tight                                  */
   HC_TAP_SQSUM = 2,     /* i32 [(h+1)][(w+1)] tight                                  */
   HC_TAP_VNF = 3,       /* f32 [ny][nx], 0 = not evaluable                           */
-  HC_TAP_STAGES = 4     /* i8  [ceil(szw_h/ystep)][nx]: -2 unvisited, -1 not evaluable,
+  HC_TAP_STAGES = 4,    /* i8  [ceil(szw_h/ystep)][nx]: -2 unvisited, -1 not evaluable,
                            k = stages passed (nstages = detection)                   */
+  HC_TAP_FACE_MASK = 5, /* u8  [rows][cols] skin mask of the detectFaces path (level ignored) */
+  HC_TAP_FACE_GRAY = 6  /* u8  [rows][cols] equalised gray & mask (level ignored)            */
 } hc_tap;
 /* Taps of kind HC_TAP_STAGES are only recorded when enabled before the enqueue. */
 HC_API int hc_context_enable_stage_taps(hc_context* ctx, int enable);

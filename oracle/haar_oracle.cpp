@@ -682,6 +682,66 @@ int orc_detect_many(const orc_cascade* c, const uint8_t* frames, int nframes, in
   return err;
 }
 
+// FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43), OpenCV 8-bit paths per SURVEY A.13
+int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step, const int lower[3],
+                     const int upper[3], double scale_factor, orc_rect* out, int cap, int* out_count,
+                     uint8_t* mask_tap, uint8_t* gray_tap) {
+  const int shift = 14, half = 1 << (shift - 1);
+  const int B2Y = 1868, G2Y = 9617, R2Y = 4899, YCRI = 11682, YCBI = 9241, delta = 128 << shift;
+  std::vector<uint8_t> mask((size_t)rows * cols), gray((size_t)rows * cols);
+  std::vector<int> hist(256, 0);
+  auto sat8 = [](int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); };
+  for (int y = 0; y < rows; y++) {
+    const uint8_t* p = bgr + (size_t)y * step;
+    for (int x = 0; x < cols; x++) {
+      const int b = p[3 * x], g = p[3 * x + 1], r = p[3 * x + 2];
+      const int Y = (b * B2Y + g * G2Y + r * R2Y + half) >> shift;       // cvtColor(BGR2YCrCb).Y == cvtColor(BGR2GRAY)
+      const int Cr = sat8(((r - Y) * YCRI + delta + half) >> shift);
+      const int Cb = sat8(((b - Y) * YCBI + delta + half) >> shift);
+      const bool in = Y >= lower[0] && Y <= upper[0] && Cr >= lower[1] && Cr <= upper[1] && Cb >= lower[2] && Cb <= upper[2];
+      mask[(size_t)y * cols + x] = in ? 255 : 0;                          // inRange
+      gray[(size_t)y * cols + x] = (uint8_t)Y;
+      hist[Y]++;
+    }
+  }
+  // equalizeHist
+  const int total = rows * cols;
+  int i0 = 0;
+  while (!hist[i0]) ++i0;
+  uint8_t lut[256] = {0};
+  if (hist[i0] == total) {
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i0;                   // dst.setTo(i)
+  } else {
+    const float scale = 255.f / (float)(total - hist[i0]);
+    int sum = 0;
+    lut[i0] = 0;
+    for (int i = i0 + 1; i < 256; i++) {
+      sum += hist[i];
+      lut[i] = (uint8_t)sat8(cv_round((float)sum * scale));               // saturate_cast<uchar>(sum * scale)
+    }
+  }
+  for (size_t i = 0; i < gray.size(); i++) gray[i] = lut[gray[i]] & mask[i];   // equalizeHist; gray &= mask
+  if (mask_tap) memcpy(mask_tap, mask.data(), mask.size());
+  if (gray_tap) memcpy(gray_tap, gray.data(), gray.size());
+  std::vector<orc_rect> faces;
+  int rc = detect_impl(c, gray.data(), rows, cols, cols, scale_factor, 2, 30, 30, 0, 0, faces, nullptr, nullptr, 0);
+  if (rc) return rc;
+  int n = 0;
+  for (const orc_rect& r : faces) {
+    // double m = norm(mean(croppedMask)); if (m/256 < 0.8) continue;
+    long long sum = 0;
+    for (int y = r.y; y < r.y + r.h; y++)
+      for (int x = r.x; x < r.x + r.w; x++) sum += mask[(size_t)y * cols + x];
+    const double mean0 = (double)sum * (1. / ((double)r.w * r.h));        // cv::mean: sum * (1./N)
+    const double m = std::sqrt(mean0 * mean0);                            // cv::norm(Scalar): sqrt of sum of squares
+    if (m / 256 < 0.8) continue;
+    if (n >= cap) return -3;
+    out[n++] = r;
+  }
+  *out_count = n;
+  return 0;
+}
+
 int orc_eval_patch(const orc_cascade* c, const uint8_t* patch, double* margins) {
   std::vector<int32_t> sum((size_t)(c->win_w + 1) * (c->win_h + 1)), sq(sum.size());
   integral_32s(patch, c->win_h, c->win_w, c->win_w, sum.data(), sq.data());

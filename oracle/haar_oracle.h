@@ -96,6 +96,16 @@ int orc_detect_many(const orc_cascade* c, const uint8_t* frames, int nframes, in
                     double scale_factor, int min_neighbors, int min_w, int min_h, int max_w, int max_h,
                     int nthreads, int32_t* counts);
 
+/* ---- the caller of the path: FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43)
+ * frame: 8UC3 BGR, rows x cols, `step` bytes per row.  lower/upper: YCrCb skin bounds
+ * (cfg.detection.skin_lower/upper, defaults (0,133,77)-(255,173,127) at src/structure.cc:75-82).
+ * Pre-steps: cvtColor BGR->YCrCb + inRange -> mask; cvtColor BGR->GRAY; equalizeHist;
+ * gray &= mask; then detectMultiScale(gray, faces, scale, 2, flags, Size(30,30)); then keep a rect
+ * iff norm(mean(mask(roi)))/256 >= 0.8.  Optional taps: mask and the masked equalised gray (tight). */
+int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step,
+                     const int lower[3], const int upper[3], double scale_factor,
+                     orc_rect* out, int cap, int* out_count, uint8_t* mask_tap, uint8_t* gray_tap);
+
 /* Evaluate one window-sized patch (win_h x win_w, tight) at scale 1: returns number of
  * stages passed (nstages = accepted), -1 if not evaluable. margins (optional, nstages
  * doubles) receive stage_sum - stage_threshold for every stage evaluated regardless of

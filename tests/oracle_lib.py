@@ -59,6 +59,8 @@ def lib():
         L.orc_detect_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_int] * 6 + \
                                      [C.c_void_p]
         L.orc_eval_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_detect_faces.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                       C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -134,6 +136,22 @@ class OracleCascade:
                 o += a * b
             res.append(per)
         return res
+
+    def detect_faces(self, bgr, lower=(0, 133, 77), upper=(255, 173, 127), scale=1.1, want_taps=False, cap=4096):
+        """FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) -> rects [, mask, gray]"""
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        rows, cols, _ = bgr.shape
+        lo = (C.c_int * 3)(*lower)
+        hi = (C.c_int * 3)(*upper)
+        out = np.zeros((cap, 4), np.int32)
+        n = C.c_int()
+        mask = np.zeros((rows, cols), np.uint8)
+        gray = np.zeros((rows, cols), np.uint8)
+        rc = lib().orc_detect_faces(self._h, bgr.ctypes.data, rows, cols, bgr.strides[0], lo, hi, scale, out.ctypes.data,
+                                    cap, C.byref(n), mask.ctypes.data, gray.ctypes.data)
+        if rc:
+            raise RuntimeError("orc_detect_faces %d" % rc)
+        return (out[:n.value].copy(), mask, gray) if want_taps else out[:n.value].copy()
 
     def detect_many(self, frames, sf=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), nthreads=1):
         frames = np.ascontiguousarray(frames, np.uint8)

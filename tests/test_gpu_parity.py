@@ -350,3 +350,36 @@ def test_unfused_prep_kernels_agree(pkg, oracle, synth, monkeypatch):
     got = ctx.detect_host(fr[None])
     grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
     assert np.array_equal(got[0], grouped)
+
+
+def test_detect_faces_path(pkg, oracle, synth):
+    """SURVEY 8f-1: FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) on device --
+    skin mask, equalised masked gray, the cascade call and the skin-ratio post-filter -- against the
+    oracle's restatement: mask bytes, gray bytes and the surviving rectangles are bit-exact."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted_bgr(240, 320, synth.frame_seed(i), nfaces=3, min_size=40, max_size=110)[0]
+                       for i in range(3)])
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=4, cand_capacity=1 << 14)
+    ctx.enable_faces()
+    got = ctx.faces_host(frames)
+    nkept = 0
+    for f in range(3):
+        want, mask, gray = oc.detect_faces(frames[f], want_taps=True)
+        assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_MASK), mask)
+        assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_GRAY), gray)
+        assert np.array_equal(got[f], want)
+        nkept += len(want)
+        # the unfiltered call on the same gray finds at least as many boxes
+        allb, _ = oc.detect(gray, 1.1, 2, (30, 30))
+        assert len(allb) >= len(want)
+    assert nkept > 0
+    # synchronous single-frame form, custom bounds, non-contiguous rows
+    big = np.zeros((240, 330, 3), np.uint8)
+    big[:, :320] = frames[0]
+    view = big[:, :320]
+    lo, hi = (10, 135, 80), (250, 170, 125)
+    assert np.array_equal(casc.detect_faces(view, lo, hi, 1.1), oc.detect_faces(frames[0], lo, hi, 1.1))
+    const = np.full((120, 160, 3), 90, np.uint8)
+    assert len(casc.detect_faces(const)) == 0

@@ -28,7 +28,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhip_cascade.so")
 
 HC_NKERNELS = 5
-TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES = range(5)
+TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES, TAP_FACE_MASK, TAP_FACE_GRAY = range(7)
+SKIN_LOWER, SKIN_UPPER = (0, 133, 77), (255, 173, 127)      # reference src/structure.cc:75-82 defaults
 
 STATUS = {0: "HC_OK", -1: "HC_ERR_IO", -2: "HC_ERR_FORMAT", -3: "HC_ERR_ARG", -4: "HC_ERR_UNSUPPORTED",
           -5: "HC_ERR_NO_DEVICE", -6: "HC_ERR_HIP", -7: "HC_ERR_CAPACITY", -8: "HC_ERR_CAND_OVERFLOW",
@@ -71,6 +72,13 @@ _SIGS = {
     "hc_detect_batch_enqueue_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "hc_detect_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hc_batch_raw_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hc_detect_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
+                                  C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "hc_context_enable_faces": (C.c_int, [C.c_void_p]),
+    "hc_faces_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
+    "hc_faces_batch_enqueue_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
+                                              C.c_void_p]),
+    "hc_faces_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hc_context_levels": (C.c_int, [C.c_void_p, C.POINTER(Level), C.c_int, C.POINTER(C.c_int)]),
     "hc_context_algorithmic_bytes": (C.c_int64, [C.c_void_p]),
     "hc_plan_query": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 4 +
@@ -142,6 +150,17 @@ class Cascade:
                                  max_size[1], buf, 256, C.byref(n), C.byref(ab)))
         return [buf[i] for i in range(n.value)], ab.value
 
+    def detect_faces(self, bgr, lower=SKIN_LOWER, upper=SKIN_UPPER, scale=1.1, capacity=4096):
+        """FaceDetector::detectFaces(frame, rects) (reference src/tracker/detector.cc:10-43)"""
+        bgr = np.asarray(bgr)
+        if bgr.dtype != np.uint8 or bgr.ndim != 3 or bgr.shape[2] != 3 or bgr.strides[1] != 3 or bgr.strides[2] != 1:
+            raise ValueError("need an HxWx3 uint8 BGR image with packed pixels")
+        out = np.zeros((capacity, 4), np.int32)
+        n = C.c_int()
+        _check(lib.hc_detect_faces(self._h, bgr.ctypes.data, bgr.shape[0], bgr.shape[1], bgr.strides[0], _i3(lower),
+                                   _i3(upper), scale, out.ctypes.data, capacity, C.byref(n)))
+        return out[:n.value].copy()
+
     def detect_multiscale(self, gray, scale_factor=1.1, min_neighbors=3, flags=0, min_size=(0, 0), max_size=(0, 0),
                           capacity=4096):
         """detectMultiScale(image, scaleFactor, minNeighbors, flags, minSize, maxSize) -> (K,4) int32 x,y,w,h."""
@@ -154,6 +173,10 @@ class Cascade:
                                         scale_factor, min_neighbors, flags, min_size[0], min_size[1], max_size[0],
                                         max_size[1], out.ctypes.data, capacity, C.byref(n)))
         return out[:n.value].copy()
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
 
 
 class Context:
@@ -222,6 +245,25 @@ class Context:
     def detect_host(self, frames):
         self.enqueue_host(frames)
         return self.wait(len(frames))
+
+    def enable_faces(self):
+        _check(lib.hc_context_enable_faces(self._h))
+
+    def faces_host(self, bgr_frames, lower=SKIN_LOWER, upper=SKIN_UPPER, capacity=1 << 14):
+        """FaceDetector::detectFaces on a batch of BGR frames [n][rows][cols][3] -> list of (K,4) rects"""
+        fr = np.ascontiguousarray(bgr_frames, np.uint8)
+        assert fr.ndim == 4 and fr.shape[1:] == (self.rows, self.cols, 3)
+        _check(lib.hc_faces_batch_enqueue_host(self._h, fr.ctypes.data, fr.strides[0], fr.strides[1], fr.shape[0],
+                                               _i3(lower), _i3(upper)))
+        out = np.zeros((capacity, 4), np.int32)
+        ofs = np.zeros(fr.shape[0] + 1, np.int32)
+        _check(lib.hc_faces_batch_wait(self._h, out.ctypes.data, capacity, ofs.ctypes.data))
+        return [out[ofs[i]:ofs[i + 1]].copy() for i in range(fr.shape[0])]
+
+    def read_face_tap(self, frame, what):
+        a = np.zeros((self.rows, self.cols), np.uint8)
+        _check(lib.hc_context_read_tap(self._h, frame, 0, what, a.ctypes.data, a.nbytes))
+        return a
 
     def enable_stage_taps(self, on=True):
         _check(lib.hc_context_enable_stage_taps(self._h, int(on)))

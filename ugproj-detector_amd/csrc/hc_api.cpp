@@ -164,6 +164,18 @@ struct hc_context {
   unsigned long long* h_cand = nullptr;
   unsigned int* h_count = nullptr;
 
+  // FaceDetector::detectFaces path (reference src/tracker/detector.cc:10-43)
+  bool faces_enabled = false, faces_pending = false;
+  uint8_t *d_bgr = nullptr, *d_gray = nullptr, *d_mask = nullptr, *d_lut = nullptr;
+  uint32_t *d_hist = nullptr, *d_msum = nullptr, *d_boxsums = nullptr;
+  int* d_boxes = nullptr;
+  hc::DevLevel* d_idlevel = nullptr;      // identity "level" (w = cols, h = rows) for the mask integral
+  uint32_t *d_idx = nullptr, *d_idy = nullptr;
+  int* h_boxes = nullptr;                 // pinned: {frame, x, y, w, h} per grouped rect
+  uint32_t* h_boxsums = nullptr;
+  int box_cap = 0, mask_pitch = 0;
+  size_t mask_int_words = 0;
+
   int pending = 0;               // frames enqueued and not yet waited
   int last_frames = 0;
   bool taps_enabled = false, timing_enabled = false, timed_last = false;
@@ -185,6 +197,14 @@ struct hc_context {
     if (h_cand) (void)hipHostFree(h_cand);
     if (h_count) (void)hipHostFree(h_count);
     h_cand = nullptr; h_count = nullptr;
+    void* fptrs[] = {d_bgr, d_gray, d_mask, d_lut, d_hist, d_msum, d_boxsums, d_boxes, d_idlevel, d_idx, d_idy};
+    for (void* q : fptrs) if (q) (void)hipFree(q);
+    d_bgr = d_gray = d_mask = d_lut = nullptr; d_hist = d_msum = d_boxsums = nullptr; d_boxes = nullptr;
+    d_idlevel = nullptr; d_idx = d_idy = nullptr;
+    if (h_boxes) (void)hipHostFree(h_boxes);
+    if (h_boxsums) (void)hipHostFree(h_boxsums);
+    h_boxes = nullptr; h_boxsums = nullptr;
+    faces_enabled = faces_pending = false;
     configured = false;
   }
 };
@@ -560,10 +580,11 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   return enqueue_device(ctx, ctx->d_frames, rows * cols, cols, nframes);
 }
 
-int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
-  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
-  if (!ctx->pending) return set_err(HC_ERR_STATE, "no batch enqueued");
-  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
+}  // extern "C"
+
+namespace {
+// waits for the enqueued batch and groups its candidates: grouped[f] = boxes of frame f
+int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   HIPCHK(hipSetDevice(ctx->device));
   const int nframes = ctx->pending;
   ctx->pending = 0;
@@ -596,7 +617,7 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
     first[nframes] = i;
   }
   ctx->last_raw.resize(count);
-  std::vector<std::vector<hc_rect>> grouped(nframes);
+  grouped.assign(nframes, {});
   auto do_frame = [&](int f) {
     std::vector<hc_rect>& grp = grouped[f];
     grp.reserve(first[f + 1] - first[f]);
@@ -618,14 +639,179 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
   } else {
     for (int f = 0; f < nframes; f++) do_frame(f);
   }
+  for (int f = 0; f < nframes; f++) ctx->last_raw_ofs[f + 1] = (int32_t)first[f + 1];
+  return HC_OK;
+}
+
+int emit(const std::vector<std::vector<hc_rect>>& grouped, hc_rect* out, int out_capacity, int32_t* offsets) {
   int total = 0;
+  const int nframes = (int)grouped.size();
   for (int f = 0; f < nframes; f++) {
-    ctx->last_raw_ofs[f + 1] = (int32_t)first[f + 1];
     offsets[f] = total;
     if (total + (int)grouped[f].size() > out_capacity) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
     for (const hc_rect& r : grouped[f]) out[total++] = r;
   }
   offsets[nframes] = total;
+  return HC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!ctx->pending) return set_err(HC_ERR_STATE, "no batch enqueued");
+  if (ctx->faces_pending) return set_err(HC_ERR_STATE, "a detectFaces batch is pending: call hc_faces_batch_wait");
+  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
+  std::vector<std::vector<hc_rect>> grouped;
+  int rc = wait_core(ctx, grouped);
+  if (rc != HC_OK) return rc;
+  return emit(grouped, out, out_capacity, offsets);
+}
+
+// ---- FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) ------------------------------
+int hc_context_enable_faces(hc_context* ctx) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (ctx->faces_enabled) return HC_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t B = (size_t)ctx->max_batch, rows = ctx->plan.rows, cols = ctx->plan.cols, npix = rows * cols;
+  ctx->mask_pitch = (int)((cols + 1 + 15) / 16 * 16);
+  ctx->mask_int_words = (size_t)ctx->mask_pitch * (rows + 1);
+  ctx->box_cap = 256 * ctx->max_batch;
+  int rc;
+  if ((rc = dev_alloc(&ctx->d_bgr, B * npix * 3))) return rc;
+  if ((rc = dev_alloc(&ctx->d_gray, B * npix))) return rc;
+  if ((rc = dev_alloc(&ctx->d_mask, B * npix))) return rc;
+  if ((rc = dev_alloc(&ctx->d_lut, B * 256))) return rc;
+  if ((rc = dev_alloc(&ctx->d_hist, B * 256))) return rc;
+  if ((rc = dev_alloc(&ctx->d_msum, B * ctx->mask_int_words))) return rc;
+  if ((rc = dev_alloc(&ctx->d_boxsums, (size_t)ctx->box_cap))) return rc;
+  if ((rc = dev_alloc(&ctx->d_boxes, (size_t)ctx->box_cap * 5))) return rc;
+  HIPCHK(hipMemset(ctx->d_msum, 0, B * ctx->mask_int_words * 4));          // row 0 / column 0 stay zero
+  // identity "pyramid level": the mask integral reuses k_pyramid_integral at scale 1
+  hc::DevLevel L{};
+  L.scale = 1.f; L.w = (int)cols; L.h = (int)rows; L.ystep = 1; L.int_pitch = ctx->mask_pitch;
+  std::vector<hc::DevLevel> lv(1, L);
+  std::vector<uint32_t> idx, idy;
+  hc::build_resize_table((int)cols, (int)cols, idx);
+  hc::build_resize_table((int)rows, (int)rows, idy);
+  if ((rc = dev_upload(&ctx->d_idlevel, lv))) return rc;
+  if ((rc = dev_upload(&ctx->d_idx, idx))) return rc;
+  if ((rc = dev_upload(&ctx->d_idy, idy))) return rc;
+  HIPCHK(hipHostMalloc((void**)&ctx->h_boxes, (size_t)ctx->box_cap * 5 * sizeof(int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->h_boxsums, (size_t)ctx->box_cap * sizeof(uint32_t), hipHostMallocDefault));
+  ctx->faces_enabled = true;
+  return HC_OK;
+}
+
+static int faces_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride, size_t row_step, int nframes,
+                         const int lower[3], const int upper[3]) {
+  hc::SkinBounds sb{};
+  for (int k = 0; k < 3; k++) { sb.lo[k] = lower[k]; sb.hi[k] = upper[k]; }
+  const size_t npix = (size_t)ctx->plan.rows * ctx->plan.cols;
+  int e = hc::launch_face_prep(ctx->stream, nframes, d_bgr, frame_stride, row_step, ctx->plan.rows, ctx->plan.cols, sb,
+                               ctx->d_gray, ctx->d_mask, npix, ctx->d_hist, ctx->d_lut);
+  if (e) return set_err(HC_ERR_HIP, std::string("face prep launch: ") + hipGetErrorString((hipError_t)e));
+  // integral of the mask (sum only) for the skin-ratio post-filter
+  e = hc::launch_pyramid_integral(ctx->stream, nframes, 1, ctx->plan.cols, ctx->d_mask, npix, ctx->plan.cols, ctx->plan.rows,
+                                  ctx->plan.cols, ctx->d_idlevel, ctx->d_idx, ctx->d_idy, ctx->d_msum, nullptr,
+                                  ctx->mask_int_words, nullptr, 0);
+  if (e) return set_err(HC_ERR_HIP, std::string("mask integral launch: ") + hipGetErrorString((hipError_t)e));
+  int rc = enqueue_device(ctx, ctx->d_gray, npix, ctx->plan.cols, nframes);
+  if (rc == HC_OK) ctx->faces_pending = true;
+  return rc;
+}
+
+int hc_faces_batch_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride_bytes, size_t row_step_bytes,
+                           int nframes, const int lower[3], const int upper[3]) {
+  if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
+  if (!d_bgr || !lower || !upper || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad argument");
+  if (row_step_bytes < (size_t)ctx->plan.cols * 3) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
+  HIPCHK(hipSetDevice(ctx->device));
+  return faces_enqueue(ctx, d_bgr, frame_stride_bytes, row_step_bytes, nframes, lower, upper);
+}
+
+int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t frame_stride_bytes, size_t row_step_bytes,
+                                int nframes, const int lower[3], const int upper[3]) {
+  if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
+  if (!h_bgr || !lower || !upper || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad argument");
+  if (row_step_bytes < (size_t)ctx->plan.cols * 3) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t rows = ctx->plan.rows, rowb = (size_t)ctx->plan.cols * 3;
+  for (int f = 0; f < nframes; f++)
+    HIPCHK(hipMemcpy2DAsync(ctx->d_bgr + (size_t)f * rows * rowb, rowb, h_bgr + (size_t)f * frame_stride_bytes,
+                            row_step_bytes, rowb, rows, hipMemcpyHostToDevice, ctx->stream));
+  return faces_enqueue(ctx, ctx->d_bgr, rows * rowb, rowb, nframes, lower, upper);
+}
+
+int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!ctx->pending || !ctx->faces_pending) return set_err(HC_ERR_STATE, "no detectFaces batch enqueued");
+  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
+  ctx->faces_pending = false;
+  std::vector<std::vector<hc_rect>> grouped;
+  int rc = wait_core(ctx, grouped);
+  if (rc != HC_OK) return rc;
+  // skin post-filter (detector.cc:33-42): m = norm(mean(mask(roi))); keep iff !(m/256 < 0.8)
+  int nb = 0;
+  for (size_t f = 0; f < grouped.size(); f++)
+    for (const hc_rect& r : grouped[f]) {
+      if (nb >= ctx->box_cap) return set_err(HC_ERR_CAPACITY, "too many rectangles for the skin filter workspace");
+      int* b = ctx->h_boxes + 5 * nb++;
+      b[0] = (int)f; b[1] = r.x; b[2] = r.y; b[3] = r.width; b[4] = r.height;
+    }
+  if (nb) {
+    HIPCHK(hipMemcpyAsync(ctx->d_boxes, ctx->h_boxes, (size_t)nb * 5 * sizeof(int), hipMemcpyHostToDevice, ctx->copy_stream));
+    int e = hc::launch_box_mask_sums(ctx->copy_stream, ctx->d_msum, ctx->mask_int_words, ctx->mask_pitch, ctx->d_boxes, nb,
+                                     ctx->d_boxsums);
+    if (e) return set_err(HC_ERR_HIP, std::string("k_box_mask_sums launch: ") + hipGetErrorString((hipError_t)e));
+    HIPCHK(hipMemcpyAsync(ctx->h_boxsums, ctx->d_boxsums, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+  }
+  int k = 0;
+  for (auto& g : grouped) {
+    std::vector<hc_rect> keep;
+    for (const hc_rect& r : g) {
+      const double mean0 = (double)ctx->h_boxsums[k++] * (1. / ((double)r.width * r.height));   // cv::mean
+      const double m = std::sqrt(mean0 * mean0);                                               // cv::norm(Scalar)
+      if (m / 256 < 0.8) continue;
+      keep.push_back(r);
+    }
+    g.swap(keep);
+  }
+  return emit(grouped, out, out_capacity, offsets);
+}
+
+int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step_bytes, const int lower[3],
+                    const int upper[3], double scale_factor, hc_rect* out, int out_capacity, int* out_count) {
+  if (!c || !bgr || !lower || !upper || !out_count) return set_err(HC_ERR_ARG, "null argument");
+  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
+  *out_count = 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  int dev = 0, ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+  HIPCHK(hipGetDevice(&dev));
+  hc_context* ctx = c->default_ctx;
+  if (ctx && ctx->device != dev) { hc_context_destroy(ctx); ctx = c->default_ctx = nullptr; }
+  int rc;
+  if (!ctx) {
+    if ((rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
+    c->default_ctx = ctx;
+  }
+  const hc::Plan& P = ctx->plan;
+  // the reference's literals: minNeighbors 2, minSize 30x30, maxSize unset (detector.cc:28-31)
+  if (!ctx->configured || P.rows != rows || P.cols != cols || P.scale_factor != scale_factor || P.min_w != 30 ||
+      P.min_h != 30 || P.max_w != cols || P.max_h != rows || ctx->min_neighbors != 2) {
+    if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, 2, 30, 30, 0, 0, 1, 1 << 16))) return rc;
+  }
+  if ((rc = hc_context_enable_faces(ctx))) return rc;
+  if ((rc = hc_faces_batch_enqueue_host(ctx, bgr, 0, step_bytes, 1, lower, upper))) return rc;
+  int32_t ofs[2] = {0, 0};
+  if ((rc = hc_faces_batch_wait(ctx, out, out_capacity, ofs))) return rc;
+  *out_count = ofs[1];
   return HC_OK;
 }
 
@@ -682,11 +868,12 @@ int hc_context_enable_stage_taps(hc_context* ctx, int enable) {
 int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* dst, size_t dst_bytes) {
   if (!ctx || !ctx->configured || !dst) return set_err(HC_ERR_STATE, "context not configured");
   if (ctx->pending) return set_err(HC_ERR_STATE, "batch still in flight");
-  if (frame < 0 || frame >= ctx->last_frames || level < 0 || level >= (int)ctx->plan.levels.size())
+  const bool frame_tap = what == HC_TAP_FACE_MASK || what == HC_TAP_FACE_GRAY;
+  if (frame < 0 || frame >= ctx->last_frames || (!frame_tap && (level < 0 || level >= (int)ctx->plan.levels.size())))
     return set_err(HC_ERR_ARG, "frame / level out of range");
   HIPCHK(hipSetDevice(ctx->device));
   const hc::Plan& P = ctx->plan;
-  const hc::DevLevel& L = P.levels[level];
+  const hc::DevLevel& L = P.levels[frame_tap ? 0 : level];
   switch (what) {
     case HC_TAP_PYRAMID: {
       const size_t n = (size_t)L.w * L.h;
@@ -713,6 +900,14 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
       const size_t n = (size_t)L.nx * L.ny_all;
       if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
       if (n) HIPCHK(hipMemcpy(dst, ctx->d_taps + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    case HC_TAP_FACE_MASK:
+    case HC_TAP_FACE_GRAY: {
+      if (!ctx->faces_enabled) return set_err(HC_ERR_STATE, "detectFaces path not enabled");
+      const size_t n = (size_t)P.rows * P.cols;
+      if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      HIPCHK(hipMemcpy(dst, (what == HC_TAP_FACE_MASK ? ctx->d_mask : ctx->d_gray) + (size_t)frame * n, n, hipMemcpyDeviceToHost));
       return HC_OK;
     }
     default:

@@ -33,6 +33,9 @@ struct CascadeArgs {
   int8_t* taps;               // nullable: per-position stage-pass counts
 };
 
+// YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
+struct SkinBounds { int32_t lo[3], hi[3]; };
+
 // all launchers return 0 or a hipError_t value
 int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames, size_t frame_stride,
                   size_t row_step, int rows, int cols, const DevLevel* levels, const uint32_t* xtab,
@@ -42,6 +45,13 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
                             uint8_t* pyr, size_t pyr_stride);
+// FaceDetector::detectFaces pre-steps (face_kernels.hip): BGR -> mask + equalised, masked gray
+int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t frame_stride, size_t row_step, int rows,
+                     int cols, const SkinBounds& sb, uint8_t* gray, uint8_t* mask, size_t plane_stride, uint32_t* hist,
+                     uint8_t* lut);
+// boxes: nboxes x {frame, x, y, w, h}; sums[i] = sum of mask over box i
+int launch_box_mask_sums(hipStream_t st, const uint32_t* integ, size_t int_stride, int pitch, const int* boxes, int nboxes,
+                         uint32_t* sums);
 int launch_integral_rows(hipStream_t st, int nframes, int nitems, const uint8_t* pyr, size_t pyr_stride,
                          const DevLevel* levels, const WorkItem* items, uint32_t* sum, uint32_t* sq,
                          size_t int_stride);

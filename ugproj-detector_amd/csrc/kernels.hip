@@ -165,7 +165,7 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
   const uint8_t* src = frames + (size_t)frame * frame_stride;
   const uint32_t* yt_l = ytab + L.ytab_ofs;
   uint32_t* S = sum + (size_t)frame * int_stride + L.int_ofs;
-  uint32_t* Q = sq + (size_t)frame * int_stride + L.int_ofs;
+  uint32_t* Q = sq ? sq + (size_t)frame * int_stride + L.int_ofs : nullptr;   // null: sum only (mask integral)
   uint8_t* P = pyr ? pyr + (size_t)frame * pyr_stride + L.pyr_ofs : nullptr;
   uint32_t col_s[CMAX], col_q[CMAX];
 #pragma unroll
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
           cs += rs[r * lds_pitch + x];
           cq += rq[r * lds_pitch + x];
           so[(size_t)r * pitch] = cs;
-          qo[(size_t)r * pitch] = cq;
+          if (Q) qo[(size_t)r * pitch] = cq;
         }
         col_s[k] = cs; col_q[k] = cq;
       }

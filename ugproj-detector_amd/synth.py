@@ -112,6 +112,32 @@ def planted(rows, cols, seed, nfaces=8, min_size=40, max_size=None):
     return img, boxes
 
 
+def planted_bgr(rows, cols, seed, nfaces=8, min_size=40, max_size=None, skin=(150, 110)):
+    """BGR 8UC3 frame for the FaceDetector::detectFaces path: the planted gray frame as luma, neutral
+    chroma (Cr = Cb = 128, outside the default skin bounds) on the background and skin chroma
+    (Cr, Cb) = `skin` inside the planted patches plus a few decoy skin-coloured blobs without a
+    face.  Integer inverse of the BT.601 YCrCb transform; returns (bgr, boxes)."""
+    gray, boxes = planted(rows, cols, seed, nfaces, min_size, max_size)
+    cr = np.full((rows, cols), 128, np.int64)
+    cb = np.full((rows, cols), 128, np.int64)
+    for (x, y, w, h) in boxes:
+        cr[y:y + h, x:x + w] = skin[0]
+        cb[y:y + h, x:x + w] = skin[1]
+    rnd = splitmix64(seed ^ 0x5C1, 9)
+    for k in range(3):                                   # decoys: skin colour, no face
+        w = 30 + int(rnd[3 * k] % np.uint64(60))
+        x = int(rnd[3 * k + 1] % np.uint64(max(cols - w, 1)))
+        y = int(rnd[3 * k + 2] % np.uint64(max(rows - w, 1)))
+        cr[y:y + w, x:x + w] = skin[0]
+        cb[y:y + w, x:x + w] = skin[1]
+    Y = gray.astype(np.int64)
+    r = Y + (1403 * (cr - 128)) // 1000
+    g = Y - (714 * (cr - 128) + 344 * (cb - 128)) // 1000
+    b = Y + (1773 * (cb - 128)) // 1000
+    bgr = np.stack([b, g, r], axis=-1)
+    return np.clip(bgr, 0, 255).astype(np.uint8), boxes
+
+
 def make_frames(kind, n, rows, cols, first=0):
     out = np.zeros((n, rows, cols), np.uint8)
     for i in range(n):
