@@ -383,3 +383,19 @@ def test_detect_faces_path(pkg, oracle, synth):
     assert np.array_equal(casc.detect_faces(view, lo, hi, 1.1), oc.detect_faces(frames[0], lo, hi, 1.1))
     const = np.full((120, 160, 3), 90, np.uint8)
     assert len(casc.detect_faces(const)) == 0
+
+
+def test_cpp_face_detector_mirror(pkg, oracle, synth, tmp_path):
+    """hip_cascade::FaceDetector (mirror of ugproj::FaceDetector, reference src/tracker/detector.h:10-19)
+    through shim_demo --faces: same rectangles as the oracle's detectFaces."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "shim_demo")
+    bgr, _ = synth.planted_bgr(240, 320, synth.frame_seed(1), nfaces=3, min_size=40, max_size=110)
+    f = tmp_path / "frame.bgr"
+    bgr.tofile(f)
+    r = subprocess.run([demo, "--faces", oracle.cascade_path("alt"), str(f), "240", "320"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
+    want = oracle.OracleCascade(oracle.cascade_path("alt")).detect_faces(bgr)
+    assert np.array_equal(got, want) and len(want) > 0

@@ -42,6 +42,8 @@ inline int mat_rows(const Mat& m) { return m.rows; }
 inline int mat_cols(const Mat& m) { return m.cols; }
 inline size_t mat_step(const Mat& m) { return m.step; }
 inline bool mat_is_u8c1(const Mat& m) { return m.type() == CV_8UC1; }
+inline bool mat_is_u8c3(const Mat& m) { return m.type() == CV_8UC3; }
+using Scalar = cv::Scalar;
 #else
 struct Rect { int x = 0, y = 0, width = 0, height = 0; };
 struct Size {
@@ -49,19 +51,27 @@ struct Size {
   Size() = default;
   Size(int w, int h) : width(w), height(h) {}
 };
-// minimal stand-in for an 8UC1 cv::Mat view (no ownership)
+// minimal stand-in for an 8-bit cv::Mat view (no ownership); channels = 1 (gray) or 3 (BGR)
 struct Mat {
   const unsigned char* data = nullptr;
-  int rows = 0, cols = 0;
+  int rows = 0, cols = 0, nchannels = 1;
   size_t step = 0;
   Mat() = default;
-  Mat(int r, int c, const unsigned char* d, size_t s = 0) : data(d), rows(r), cols(c), step(s ? s : (size_t)c) {}
+  Mat(int r, int c, const unsigned char* d, size_t s = 0, int ch = 1)
+      : data(d), rows(r), cols(c), nchannels(ch), step(s ? s : (size_t)c * ch) {}
+};
+struct Scalar {
+  double val[4] = {0, 0, 0, 0};
+  Scalar() = default;
+  Scalar(double a, double b = 0, double c = 0, double d = 0) { val[0] = a; val[1] = b; val[2] = c; val[3] = d; }
+  double operator[](int i) const { return val[i]; }
 };
 inline const unsigned char* mat_data(const Mat& m) { return m.data; }
 inline int mat_rows(const Mat& m) { return m.rows; }
 inline int mat_cols(const Mat& m) { return m.cols; }
 inline size_t mat_step(const Mat& m) { return m.step; }
-inline bool mat_is_u8c1(const Mat&) { return true; }
+inline bool mat_is_u8c1(const Mat& m) { return m.nchannels == 1; }
+inline bool mat_is_u8c3(const Mat& m) { return m.nchannels == 3; }
 #endif
 static_assert(sizeof(Rect) == sizeof(hc_rect), "Rect must be layout-compatible with hc_rect");
 
@@ -105,6 +115,8 @@ class CascadeClassifier {
       return;
     }
   }
+
+  hc_cascade* handle() const { return h_; }   // for hip_cascade::FaceDetector
 
  private:
   hc_cascade* h_ = nullptr;

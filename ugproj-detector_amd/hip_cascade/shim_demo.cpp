@@ -9,9 +9,39 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+
 #include "cascade_classifier.hpp"
+#include "face_detector.hpp"
+
+// shim_demo --faces <cascade> <frame.bgr> <rows> <cols> [scale]: the whole FaceDetector::detectFaces
+// (reference src/tracker/detector.cc:10-43) on a raw packed BGR frame, default skin bounds.
+static int faces_main(int argc, char** argv) {
+  if (argc < 6) { fprintf(stderr, "usage: %s --faces cascade frame.bgr rows cols [scale]\n", argv[0]); return 64; }
+  hip_cascade::CascadeClassifier cascade;
+  if (!cascade.load(argv[2])) { fprintf(stderr, "cannot load cascade %s\n", argv[2]); return 1; }
+  const int rows = atoi(argv[4]), cols = atoi(argv[5]);
+  hip_cascade::DetectionSection cfg;
+  if (argc > 6) cfg.scale = atof(argv[6]);
+  std::vector<unsigned char> buf((size_t)rows * cols * 3);
+  FILE* f = fopen(argv[3], "rb");
+  if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) { fprintf(stderr, "cannot read frame\n"); return 1; }
+  fclose(f);
+  hip_cascade::Mat frame(rows, cols, buf.data(), 0, 3);
+  hip_cascade::FaceDetector detector(cascade, cfg);
+  std::vector<hip_cascade::Rect> rects;
+  try {
+    detector.detectFaces(frame, rects);
+  } catch (const std::exception& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return 2;
+  }
+  for (const auto& r : rects) printf("%d %d %d %d\n", r.x, r.y, r.width, r.height);
+  return 0;
+}
 
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--faces")) return faces_main(argc, argv);
   if (argc < 5) { fprintf(stderr, "usage: %s cascade frame.u8 rows cols [scale]\n", argv[0]); return 64; }
   hip_cascade::CascadeClassifier cascade;
   if (!cascade.load(argv[1])) { fprintf(stderr, "cannot load cascade %s\n", argv[1]); return 1; }
