@@ -113,6 +113,11 @@ HC_API int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols
                            const int lower[3], const int upper[3], double scale_factor,
                            hc_rect* out, int out_capacity, int* out_count);
 HC_API int hc_context_enable_faces(hc_context* ctx);
+/* Scan-size resize ahead of detectFaces: cv::resize(orig, curr, cfg.scan.frame_size, 0, 0, INTER_AREA)
+ * (reference src/tracker/face_tracker.cc:112-114).  After this call the faces enqueue functions take
+ * src_rows x src_cols BGR frames and decimate them on device to the configured rows x cols.  Integer
+ * decimation factors only (1280x720 -> 640x360 under the shipped cfg); otherwise HC_ERR_UNSUPPORTED. */
+HC_API int hc_context_enable_scan_resize(hc_context* ctx, int src_rows, int src_cols);
 HC_API int hc_faces_batch_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride_bytes,
                                   size_t row_step_bytes, int nframes, const int lower[3], const int upper[3]);
 HC_API int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t frame_stride_bytes,
@@ -154,7 +159,8 @@ typedef enum hc_tap {
   HC_TAP_STAGES = 4,    /* i8  [ceil(szw_h/ystep)][nx]: -2 unvisited, -1 not evaluable,
                            k = stages passed (nstages = detection)                   */
   HC_TAP_FACE_MASK = 5, /* u8  [rows][cols] skin mask of the detectFaces path (level ignored) */
-  HC_TAP_FACE_GRAY = 6  /* u8  [rows][cols] equalised gray & mask (level ignored)            */
+  HC_TAP_FACE_GRAY = 6, /* u8  [rows][cols] equalised gray & mask (level ignored)            */
+  HC_TAP_FACE_BGR = 7   /* u8  [rows][cols][3] scan-size BGR frame after the INTER_AREA resize */
 } hc_tap;
 /* Taps of kind HC_TAP_STAGES are only recorded when enabled before the enqueue. */
 HC_API int hc_context_enable_stage_taps(hc_context* ctx, int enable);

@@ -742,6 +742,22 @@ int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int col
   return 0;
 }
 
+int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t step, uint8_t* dst, int drows, int dcols) {
+  if (drows <= 0 || dcols <= 0 || rows % drows || cols % dcols || (channels != 1 && channels != 3)) return -4;
+  const int fy = rows / drows, fx = cols / dcols;
+  const float scale = 1.f / (float)(fx * fy);
+  for (int y = 0; y < drows; y++)
+    for (int x = 0; x < dcols; x++)
+      for (int ch = 0; ch < channels; ch++) {
+        int sum = 0;
+        for (int j = 0; j < fy; j++)
+          for (int i = 0; i < fx; i++) sum += src[(size_t)(y * fy + j) * step + (size_t)(x * fx + i) * channels + ch];
+        int v = (fx == 2 && fy == 2) ? (sum + 2) >> 2 : cv_round((float)sum * scale);
+        dst[((size_t)y * dcols + x) * channels + ch] = (uint8_t)(v > 255 ? 255 : v);
+      }
+  return 0;
+}
+
 int orc_eval_patch(const orc_cascade* c, const uint8_t* patch, double* margins) {
   std::vector<int32_t> sum((size_t)(c->win_w + 1) * (c->win_h + 1)), sq(sum.size());
   integral_32s(patch, c->win_h, c->win_w, c->win_w, sum.data(), sq.data());

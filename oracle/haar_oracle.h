@@ -106,6 +106,14 @@ int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int col
                      const int lower[3], const int upper[3], double scale_factor,
                      orc_rect* out, int cap, int* out_count, uint8_t* mask_tap, uint8_t* gray_tap);
 
+/* cv::resize(src, dst, dsize, 0, 0, INTER_AREA) for 8-bit images with 1 or 3 interleaved channels and
+ * an INTEGER decimation factor in each direction -- the scan-size resize of the tracker (reference
+ * src/tracker/face_tracker.cc:112-114; 1280x720 -> 640x360 under conf/apink.mrchu.720p.cfg:4).
+ * Factor 2x2: (a+b+c+d+2)>>2 (ResizeAreaFastVec); other integer factors: cvRound(sum * (1.f/area))
+ * (resizeAreaFast_).  Non-integer ratios are not restated (returns -4).  [UPSTREAM-RECALL, unpinned] */
+int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t step,
+                    uint8_t* dst, int drows, int dcols);
+
 /* Evaluate one window-sized patch (win_h x win_w, tight) at scale 1: returns number of
  * stages passed (nstages = accepted), -1 if not evaluable. margins (optional, nstages
  * doubles) receive stage_sum - stage_threshold for every stage evaluated regardless of

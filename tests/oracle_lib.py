@@ -59,6 +59,7 @@ def lib():
         L.orc_detect_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_int] * 6 + \
                                      [C.c_void_p]
         L.orc_eval_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_resize_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.orc_detect_faces.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
         _lib = L
@@ -170,6 +171,17 @@ def resize_linear_exact(img, drows, dcols):
     rc = lib().orc_resize_linear_exact(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], dst.ctypes.data,
                                        drows, dcols)
     assert rc == 0
+    return dst
+
+
+def resize_area(img, drows, dcols):
+    """cv::resize(..., INTER_AREA) for integer decimation factors; img HxW or HxWx3 uint8"""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    dst = np.zeros((drows, dcols) if ch == 1 else (drows, dcols, ch), np.uint8)
+    rc = lib().orc_resize_area(img.ctypes.data, img.shape[0], img.shape[1], ch, img.strides[0], dst.ctypes.data, drows, dcols)
+    if rc:
+        raise RuntimeError("orc_resize_area %d" % rc)
     return dst
 
 

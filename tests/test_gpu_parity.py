@@ -399,3 +399,33 @@ def test_cpp_face_detector_mirror(pkg, oracle, synth, tmp_path):
     got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
     want = oracle.OracleCascade(oracle.cascade_path("alt")).detect_faces(bgr)
     assert np.array_equal(got, want) and len(want) > 0
+
+
+def test_config1_plumbing_scan_resize_then_detect_faces(pkg, oracle, synth):
+    """BASELINE config #1 (conf/apink.mrchu.720p.cfg as shipped: scan 640x360, cascade alt2): 1280x720 BGR
+    frames -> INTER_AREA resize to the scan size (reference src/tracker/face_tracker.cc:112-114) ->
+    FaceDetector::detectFaces (src/tracker/detector.cc:10-43).  Every stage against the oracle."""
+    for name in ("alt2", "alt"):           # as shipped (cfg:10), and with the cascade BASELINE.json names
+        path = oracle.cascade_path(name)
+        casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+        frames = np.stack([synth.planted_bgr(720, 1280, synth.frame_seed(i), nfaces=6, min_size=90, max_size=260)[0]
+                           for i in range(2)])
+        ctx = pkg.Context(casc)
+        ctx.configure(360, 640, 1.1, 2, (30, 30), (0, 0), max_batch=2, cand_capacity=1 << 14)
+        assert len(ctx.levels()) == 26 and ctx.algorithmic_bytes() == 8464320
+        ctx.enable_faces()
+        ctx.enable_scan_resize(720, 1280)
+        got = ctx.faces_host(frames)
+        n = 0
+        for f in range(2):
+            small = oracle.resize_area(frames[f], 360, 640)
+            assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_BGR), small)
+            want, mask, gray = oc.detect_faces(small, want_taps=True)
+            assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_MASK), mask)
+            assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_GRAY), gray)
+            assert np.array_equal(got[f], want)
+            n += len(want)
+        assert n > 0
+    with pytest.raises(pkg.HipCascadeError) as e:
+        ctx.enable_scan_resize(700, 1280)           # 700/360 is not an integer factor
+    assert e.value.code == -4

@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhip_cascade.so")
 
 HC_NKERNELS = 5
-TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES, TAP_FACE_MASK, TAP_FACE_GRAY = range(7)
+TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES, TAP_FACE_MASK, TAP_FACE_GRAY, TAP_FACE_BGR = range(8)
 SKIN_LOWER, SKIN_UPPER = (0, 133, 77), (255, 173, 127)      # reference src/structure.cc:75-82 defaults
 
 STATUS = {0: "HC_OK", -1: "HC_ERR_IO", -2: "HC_ERR_FORMAT", -3: "HC_ERR_ARG", -4: "HC_ERR_UNSUPPORTED",
@@ -75,6 +75,7 @@ _SIGS = {
     "hc_detect_faces": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
                                   C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "hc_context_enable_faces": (C.c_int, [C.c_void_p]),
+    "hc_context_enable_scan_resize": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "hc_faces_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "hc_faces_batch_enqueue_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p,
                                               C.c_void_p]),
@@ -249,10 +250,14 @@ class Context:
     def enable_faces(self):
         _check(lib.hc_context_enable_faces(self._h))
 
+    def enable_scan_resize(self, src_rows, src_cols):
+        _check(lib.hc_context_enable_scan_resize(self._h, src_rows, src_cols))
+        self._src = (src_rows, src_cols)
+
     def faces_host(self, bgr_frames, lower=SKIN_LOWER, upper=SKIN_UPPER, capacity=1 << 14):
         """FaceDetector::detectFaces on a batch of BGR frames [n][rows][cols][3] -> list of (K,4) rects"""
         fr = np.ascontiguousarray(bgr_frames, np.uint8)
-        assert fr.ndim == 4 and fr.shape[1:] == (self.rows, self.cols, 3)
+        assert fr.ndim == 4 and fr.shape[1:] == getattr(self, "_src", (self.rows, self.cols)) + (3,)
         _check(lib.hc_faces_batch_enqueue_host(self._h, fr.ctypes.data, fr.strides[0], fr.strides[1], fr.shape[0],
                                                _i3(lower), _i3(upper)))
         out = np.zeros((capacity, 4), np.int32)
@@ -261,7 +266,7 @@ class Context:
         return [out[ofs[i]:ofs[i + 1]].copy() for i in range(fr.shape[0])]
 
     def read_face_tap(self, frame, what):
-        a = np.zeros((self.rows, self.cols), np.uint8)
+        a = np.zeros((self.rows, self.cols, 3) if what == TAP_FACE_BGR else (self.rows, self.cols), np.uint8)
         _check(lib.hc_context_read_tap(self._h, frame, 0, what, a.ctypes.data, a.nbytes))
         return a
 

@@ -91,6 +91,24 @@ __global__ __launch_bounds__(WG_THREADS) void k_apply_lut_mask(uint8_t* __restri
   }
 }
 
+// cv::resize(INTER_AREA) with integer decimation factors (reference src/tracker/face_tracker.cc:112-114):
+// one thread per destination byte (pixel x channel).  2x2: (a+b+c+d+2)>>2; else cvRound(sum * (1.f/area)).
+__global__ __launch_bounds__(WG_THREADS) void k_area_decimate(const uint8_t* __restrict__ src, size_t src_frame_stride,
+                                                              size_t src_row_step, int channels, int fx, int fy,
+                                                              uint8_t* __restrict__ dst, size_t dst_frame_stride,
+                                                              int drows, int dcols) {
+  const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+  const int rowb = dcols * channels;
+  if (i >= drows * rowb) return;
+  const int y = i / rowb, xb = i - y * rowb, x = xb / channels, ch = xb - x * channels;
+  const uint8_t* s = src + (size_t)blockIdx.y * src_frame_stride + (size_t)(y * fy) * src_row_step + (size_t)(x * fx) * channels + ch;
+  int sum = 0;
+  for (int j = 0; j < fy; j++)
+    for (int k = 0; k < fx; k++) sum += s[(size_t)j * src_row_step + (size_t)k * channels];
+  const int v = (fx == 2 && fy == 2) ? (sum + 2) >> 2 : __float2int_rn((float)sum * (1.f / (float)(fx * fy)));
+  dst[(size_t)blockIdx.y * dst_frame_stride + i] = (uint8_t)min(v, 255);
+}
+
 // sums[i] = sum of mask over rect i, from the (rows+1) x pitch integral of the mask
 __global__ void k_box_mask_sums(const uint32_t* __restrict__ integ, size_t int_stride, int pitch, const int* __restrict__ boxes,
                                 int nboxes, uint32_t* __restrict__ sums) {
@@ -118,6 +136,16 @@ int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t fra
   HC_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_apply_lut_mask, dim3((npix + 4 * WG_THREADS - 1) / (4 * WG_THREADS), nframes), dim3(WG_THREADS), 0,
                      st, gray, mask, plane_stride, npix, lut);
+  HC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_area_decimate(hipStream_t st, int nframes, const uint8_t* src, size_t src_frame_stride, size_t src_row_step,
+                         int channels, int fx, int fy, uint8_t* dst, size_t dst_frame_stride, int drows, int dcols) {
+  if (nframes == 0) return 0;
+  const int n = drows * dcols * channels;
+  hipLaunchKernelGGL(k_area_decimate, dim3((n + WG_THREADS - 1) / WG_THREADS, nframes), dim3(WG_THREADS), 0, st, src,
+                     src_frame_stride, src_row_step, channels, fx, fy, dst, dst_frame_stride, drows, dcols);
   HC_LAUNCH_CHECK();
   return 0;
 }

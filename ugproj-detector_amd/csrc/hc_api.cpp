@@ -174,6 +174,10 @@ struct hc_context {
   int* h_boxes = nullptr;                 // pinned: {frame, x, y, w, h} per grouped rect
   uint32_t* h_boxsums = nullptr;
   int box_cap = 0, mask_pitch = 0;
+  // scan-size resize (reference src/tracker/face_tracker.cc:112-114): source frames are src_rows x src_cols,
+  // decimated by INTER_AREA to the configured rows x cols before detectFaces
+  int src_rows = 0, src_cols = 0;
+  uint8_t* d_src_bgr = nullptr;
   size_t mask_int_words = 0;
 
   int pending = 0;               // frames enqueued and not yet waited
@@ -197,6 +201,8 @@ struct hc_context {
     if (h_cand) (void)hipHostFree(h_cand);
     if (h_count) (void)hipHostFree(h_count);
     h_cand = nullptr; h_count = nullptr;
+    if (d_src_bgr) (void)hipFree(d_src_bgr);
+    d_src_bgr = nullptr; src_rows = src_cols = 0;
     void* fptrs[] = {d_bgr, d_gray, d_mask, d_lut, d_hist, d_msum, d_boxsums, d_boxes, d_idlevel, d_idx, d_idy};
     for (void* q : fptrs) if (q) (void)hipFree(q);
     d_bgr = d_gray = d_mask = d_lut = nullptr; d_hist = d_msum = d_boxsums = nullptr; d_boxes = nullptr;
@@ -704,8 +710,29 @@ int hc_context_enable_faces(hc_context* ctx) {
   return HC_OK;
 }
 
+int hc_context_enable_scan_resize(hc_context* ctx, int src_rows, int src_cols) {
+  if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
+  if (src_rows <= 0 || src_cols <= 0 || src_rows % ctx->plan.rows || src_cols % ctx->plan.cols)
+    return set_err(HC_ERR_UNSUPPORTED, "INTER_AREA scan resize supports integer decimation factors only");
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->d_src_bgr) (void)hipFree(ctx->d_src_bgr);
+  ctx->d_src_bgr = nullptr;
+  int rc = dev_alloc(&ctx->d_src_bgr, (size_t)ctx->max_batch * src_rows * src_cols * 3);
+  if (rc) return rc;
+  ctx->src_rows = src_rows;
+  ctx->src_cols = src_cols;
+  return HC_OK;
+}
+
 static int faces_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride, size_t row_step, int nframes,
                          const int lower[3], const int upper[3]) {
+  if (ctx->src_rows) {   // cv::resize(orig, curr, scan.frame_size, 0, 0, INTER_AREA) first
+    const size_t drow = (size_t)ctx->plan.cols * 3, dframe = drow * ctx->plan.rows;
+    int e = hc::launch_area_decimate(ctx->stream, nframes, d_bgr, frame_stride, row_step, 3, ctx->src_cols / ctx->plan.cols,
+                                     ctx->src_rows / ctx->plan.rows, ctx->d_bgr, dframe, ctx->plan.rows, ctx->plan.cols);
+    if (e) return set_err(HC_ERR_HIP, std::string("k_area_decimate launch: ") + hipGetErrorString((hipError_t)e));
+    d_bgr = ctx->d_bgr; frame_stride = dframe; row_step = drow;
+  }
   hc::SkinBounds sb{};
   for (int k = 0; k < 3; k++) { sb.lo[k] = lower[k]; sb.hi[k] = upper[k]; }
   const size_t npix = (size_t)ctx->plan.rows * ctx->plan.cols;
@@ -726,7 +753,7 @@ int hc_faces_batch_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_s
                            int nframes, const int lower[3], const int upper[3]) {
   if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
   if (!d_bgr || !lower || !upper || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad argument");
-  if (row_step_bytes < (size_t)ctx->plan.cols * 3) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  if (row_step_bytes < (size_t)(ctx->src_cols ? ctx->src_cols : ctx->plan.cols) * 3) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
   return faces_enqueue(ctx, d_bgr, frame_stride_bytes, row_step_bytes, nframes, lower, upper);
@@ -736,14 +763,16 @@ int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t fr
                                 int nframes, const int lower[3], const int upper[3]) {
   if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
   if (!h_bgr || !lower || !upper || nframes <= 0 || nframes > ctx->max_batch) return set_err(HC_ERR_ARG, "bad argument");
-  if (row_step_bytes < (size_t)ctx->plan.cols * 3) return set_err(HC_ERR_ARG, "row step smaller than the row");
+  const size_t rows = ctx->src_rows ? ctx->src_rows : ctx->plan.rows;
+  const size_t rowb = (size_t)(ctx->src_cols ? ctx->src_cols : ctx->plan.cols) * 3;
+  if (row_step_bytes < rowb) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
-  const size_t rows = ctx->plan.rows, rowb = (size_t)ctx->plan.cols * 3;
+  uint8_t* stage = ctx->src_rows ? ctx->d_src_bgr : ctx->d_bgr;
   for (int f = 0; f < nframes; f++)
-    HIPCHK(hipMemcpy2DAsync(ctx->d_bgr + (size_t)f * rows * rowb, rowb, h_bgr + (size_t)f * frame_stride_bytes,
+    HIPCHK(hipMemcpy2DAsync(stage + (size_t)f * rows * rowb, rowb, h_bgr + (size_t)f * frame_stride_bytes,
                             row_step_bytes, rowb, rows, hipMemcpyHostToDevice, ctx->stream));
-  return faces_enqueue(ctx, ctx->d_bgr, rows * rowb, rowb, nframes, lower, upper);
+  return faces_enqueue(ctx, stage, rows * rowb, rowb, nframes, lower, upper);
 }
 
 int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
@@ -868,7 +897,7 @@ int hc_context_enable_stage_taps(hc_context* ctx, int enable) {
 int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* dst, size_t dst_bytes) {
   if (!ctx || !ctx->configured || !dst) return set_err(HC_ERR_STATE, "context not configured");
   if (ctx->pending) return set_err(HC_ERR_STATE, "batch still in flight");
-  const bool frame_tap = what == HC_TAP_FACE_MASK || what == HC_TAP_FACE_GRAY;
+  const bool frame_tap = what == HC_TAP_FACE_MASK || what == HC_TAP_FACE_GRAY || what == HC_TAP_FACE_BGR;
   if (frame < 0 || frame >= ctx->last_frames || (!frame_tap && (level < 0 || level >= (int)ctx->plan.levels.size())))
     return set_err(HC_ERR_ARG, "frame / level out of range");
   HIPCHK(hipSetDevice(ctx->device));
@@ -900,6 +929,13 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
       const size_t n = (size_t)L.nx * L.ny_all;
       if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
       if (n) HIPCHK(hipMemcpy(dst, ctx->d_taps + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
+      return HC_OK;
+    }
+    case HC_TAP_FACE_BGR: {
+      if (!ctx->faces_enabled) return set_err(HC_ERR_STATE, "detectFaces path not enabled");
+      const size_t n = (size_t)P.rows * P.cols * 3;
+      if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      HIPCHK(hipMemcpy(dst, ctx->d_bgr + (size_t)frame * n, n, hipMemcpyDeviceToHost));
       return HC_OK;
     }
     case HC_TAP_FACE_MASK:

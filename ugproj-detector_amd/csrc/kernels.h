@@ -49,6 +49,9 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
 int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t frame_stride, size_t row_step, int rows,
                      int cols, const SkinBounds& sb, uint8_t* gray, uint8_t* mask, size_t plane_stride, uint32_t* hist,
                      uint8_t* lut);
+// INTER_AREA decimation by integer factors (scan-size resize of the tracker)
+int launch_area_decimate(hipStream_t st, int nframes, const uint8_t* src, size_t src_frame_stride, size_t src_row_step,
+                         int channels, int fx, int fy, uint8_t* dst, size_t dst_frame_stride, int drows, int dcols);
 // boxes: nboxes x {frame, x, y, w, h}; sums[i] = sum of mask over box i
 int launch_box_mask_sums(hipStream_t st, const uint32_t* integ, size_t int_stride, int pitch, const int* boxes, int nboxes,
                          uint32_t* sums);
