@@ -429,3 +429,68 @@ def test_config1_plumbing_scan_resize_then_detect_faces(pkg, oracle, synth):
     with pytest.raises(pkg.HipCascadeError) as e:
         ctx.enable_scan_resize(700, 1280)           # 700/360 is not an integer factor
     assert e.value.code == -4
+
+
+def test_randomised_calls_match_oracle(pkg, oracle, synth):
+    """Property-style sweep: random geometry, scale factor, minNeighbors, min/max size, cascade and
+    stimulus family; grouped boxes and raw candidates must equal the oracle's every time."""
+    rng = np.random.default_rng(2026)
+    cascades = {n: (pkg.Cascade(oracle.cascade_path(n)), oracle.OracleCascade(oracle.cascade_path(n)))
+                for n in ("alt", "alt2", "default", "alt_tree")}
+    nboxes = 0
+    for it in range(40):
+        name = ("alt", "alt2", "default", "alt_tree")[it % 4]
+        casc, oc = cascades[name]
+        rows, cols = int(rng.integers(24, 300)), int(rng.integers(24, 400))
+        kind = it % 3
+        seed = synth.frame_seed(1000 + it)
+        if kind == 0 and rows >= 60 and cols >= 60:
+            fr = synth.planted(rows, cols, seed, nfaces=2, min_size=30, max_size=max(31, min(rows, cols) - 1))[0]
+        elif kind == 1:
+            fr = synth.texture(rows, cols, seed)
+        else:
+            fr = synth.noise(rows, cols, seed)
+        sf = float(rng.choice([1.05, 1.1, 1.15, 1.2, 1.3, 1.5, 2.0]))
+        mn = int(rng.integers(0, 4))
+        mins = (int(rng.integers(0, 50)),) * 2 if rng.integers(0, 2) else (0, 0)
+        maxs = (int(rng.integers(60, 200)),) * 2 if rng.integers(0, 3) == 0 else (0, 0)
+        ctx = pkg.Context(casc)
+        ctx.configure(rows, cols, sf, mn, mins, maxs, max_batch=1, cand_capacity=1 << 16)
+        got = ctx.detect_host(fr[None])[0]
+        raw = ctx.raw_candidates(1)[0]
+        want, wraw = oc.detect(fr, sf, mn, mins, maxs)
+        assert np.array_equal(raw, wraw), (it, name, rows, cols, sf, mn, mins, maxs)
+        assert np.array_equal(got, want), (it, name, rows, cols, sf, mn, mins, maxs)
+        nboxes += len(want)
+        ctx.close()
+    assert nboxes > 0
+
+
+def test_two_contexts_two_threads(pkg, oracle, synth):
+    """A cascade is immutable and shareable; contexts are single-caller.  Two host threads, each
+    with its own context on the same GPU, produce the same boxes as a serial run."""
+    import threading
+    path = oracle.cascade_path("alt")
+    casc = pkg.Cascade(path)
+    frames = np.stack([synth.planted(180, 240, synth.frame_seed(i), nfaces=2, min_size=40, max_size=80)[0]
+                       for i in range(6)])
+    ref = pkg.Context(casc)
+    ref.configure(180, 240, 1.1, 2, (30, 30), (0, 0), max_batch=8)
+    want = ref.detect_host(frames)
+    results, errors = {}, []
+
+    def work(tid):
+        try:
+            c = pkg.Context(casc)
+            c.configure(180, 240, 1.1, 2, (30, 30), (0, 0), max_batch=8)
+            for _ in range(5):
+                results[tid] = c.detect_host(frames)
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for tid in range(2):
+        for a, b in zip(results[tid], want):
+            assert np.array_equal(a, b)
