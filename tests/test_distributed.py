@@ -67,3 +67,20 @@ def test_gloo_gather_of_box_records(pkg, tmp_path, world):
         cnt, boxes = got[fid]
         assert cnt == len(want)
         assert boxes.tolist() == want[:shard.MAX_BOXES].tolist()
+
+
+def test_box_file_roundtrip(pkg, tmp_path):
+    """frame id -> rect list on disk, in frame order, any number of boxes per frame."""
+    import importlib
+    shard = importlib.import_module("ugproj_detector_amd.shard")
+    boxes = {7: np.array([[1, 2, 30, 30]], np.int32), 3: np.zeros((0, 4), np.int32),
+             11: np.arange(4 * 100, dtype=np.int32).reshape(100, 4)}
+    p = str(tmp_path / "boxes.hcbx")
+    shard.save_boxes(p, boxes)
+    got = shard.load_boxes(p)
+    assert list(got) == [3, 7, 11]
+    for k in boxes:
+        assert got[k].tolist() == boxes[k].tolist()
+    (tmp_path / "bad").write_bytes(b"nope")
+    with pytest.raises(ValueError):
+        shard.load_boxes(str(tmp_path / "bad"))

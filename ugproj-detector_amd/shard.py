@@ -60,3 +60,38 @@ def gather_records(rec, device=None):
     out = torch.empty((dist.get_world_size() * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
     dist.all_gather_into_tensor(out, t)
     return out.cpu().numpy()
+
+
+# ---- on-disk form of the same records, for handing detections to the sequential tracker /
+# clusterer out of band (the reference only has a TODO for tracker metadata files, src/file_io.h:41-48).
+# Layout (little endian): magic "HCBX", int32 version = 1, int32 nframes, then per frame
+# int32 frame_id, int32 count, count x int32[4] (x, y, width, height).  Frames are stored in ascending id.
+_MAGIC = b"HCBX"
+
+
+def save_boxes(path, boxes_by_frame):
+    """boxes_by_frame: dict frame_id -> (K,4) int array (all K boxes, no capacity limit)"""
+    import struct
+    with open(path, "wb") as f:
+        f.write(_MAGIC + struct.pack("<ii", 1, len(boxes_by_frame)))
+        for fid in sorted(boxes_by_frame):
+            b = np.asarray(boxes_by_frame[fid], np.int32).reshape(-1, 4)
+            f.write(struct.pack("<ii", int(fid), len(b)))
+            f.write(b.astype("<i4").tobytes())
+
+
+def load_boxes(path):
+    import struct
+    data = open(path, "rb").read()
+    if data[:4] != _MAGIC:
+        raise ValueError("not an HCBX file")
+    ver, n = struct.unpack_from("<ii", data, 4)
+    if ver != 1:
+        raise ValueError("unsupported HCBX version %d" % ver)
+    p, out = 12, {}
+    for _ in range(n):
+        fid, cnt = struct.unpack_from("<ii", data, p)
+        p += 8
+        out[fid] = np.frombuffer(data, "<i4", cnt * 4, p).reshape(cnt, 4).copy()
+        p += cnt * 16
+    return out
