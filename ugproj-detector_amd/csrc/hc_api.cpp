@@ -141,6 +141,7 @@ struct hc_context {
   int sparse_max = 32;
   bool fused_prep = true;   // k_pyramid_integral instead of k_resize + k_integral_rows + k_integral_cols
   int row_stages = 1;
+  int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
 
   // device
   uint8_t* d_frames = nullptr;   // staging for the host-input path
@@ -371,7 +372,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
       A.levels = c->d_levels; A.bands = c->d_band_items[k]; A.nbands = (int)P.band_items[k].size();
       A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
-      if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) A.nstages = std::min(A.nstages, std::max(1, atoi(e_)));   // timing experiments only
+      if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
       A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
       A.sparse_max = c->sparse_max;
       A.row_stages = c->row_stages;
@@ -486,6 +487,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   }
   if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knobs
   if (const char* e_ = getenv("HC_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e_));
+  if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) ctx->debug_max_stages = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
   if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
@@ -598,7 +600,7 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   if (ctx->timed_last && !ctx->plan.levels.empty())
     for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   unsigned int count = *ctx->h_count;
-  if (getenv("HC_DEBUG_MAX_STAGES") && count > (size_t)ctx->cand_per_frame * ctx->max_batch) count = 0;   // timing experiments only
+  if (ctx->debug_max_stages > 0 && count > (size_t)ctx->cand_per_frame * ctx->max_batch) count = 0;   // timing experiments only
   const size_t cap = (size_t)ctx->cand_per_frame * ctx->max_batch;
   ctx->last_frames = nframes;
   ctx->last_raw.clear();

@@ -145,7 +145,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_cols(
 // registers across chunks, final integral rows stored coalesced.  The pyramid never touches
 // HBM (unless the debug tap asks for it) and `sum`/`sqsum` are written exactly once:
 // HBM traffic = the algorithmic 8 B per integral element.
-constexpr int PI_THREADS = 512;   // 8 wavefronts: one pyramid row each per chunk of 8 rows
+#ifndef HC_PI_THREADS
+#define HC_PI_THREADS 512
+#endif
+constexpr int PI_THREADS = HC_PI_THREADS;   // 8 (16) wavefronts: one pyramid row each per chunk of 8 (16) rows
 constexpr int PI_UNROLL = 4;      // 64-pixel chunks whose source loads are in flight together
 
 template <int CMAX>   // columns per thread: level width <= PI_THREADS * CMAX
@@ -576,8 +579,8 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
                             uint8_t* pyr, size_t pyr_stride) {
   if (nlevels == 0 || nframes == 0) return 0;
   const int lds_pitch = (max_w + 63) & ~63;
-  int R = 8;                                     // rows per chunk: (2 R + 1) x pitch words of LDS, <= 64 KB
-  while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 > 65536) R >>= 1;
+  int R = PI_THREADS / 64;                       // rows per chunk: (2 R + 1) x pitch words of LDS, <= 64 KB (128 KB for 16 waves)
+  while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 > (PI_THREADS > 512 ? 131072u : 65536u)) R >>= 1;
   const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4;
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
 #define HC_PI(C)                                                                                                  \
