@@ -494,3 +494,32 @@ def test_two_contexts_two_threads(pkg, oracle, synth):
     for tid in range(2):
         for a, b in zip(results[tid], want):
             assert np.array_equal(a, b)
+
+
+def test_context_lifecycle_soak(pkg, oracle, synth):
+    """Create / configure / reconfigure / destroy many contexts: no leaks that exhaust HBM, no
+    stale state (every configuration still matches the oracle)."""
+    import torch
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    free0 = torch.cuda.mem_get_info()[0]
+    rng = np.random.default_rng(5)
+    ctx = pkg.Context(casc)
+    for it in range(60):
+        rows, cols = int(rng.integers(40, 400)), int(rng.integers(40, 500))
+        if it % 10 == 0:
+            ctx.close()
+            ctx = pkg.Context(casc)
+        ctx.configure(rows, cols, 1.1, 2, (0, 0), (0, 0), max_batch=int(rng.integers(1, 9)))
+        if it % 3 == 0:
+            ctx.enable_faces()
+        fr = synth.noise(rows, cols, synth.frame_seed(it))
+        if it % 6 == 0:
+            want, _ = oc.detect(fr, 1.1, 2, (0, 0))
+            assert np.array_equal(ctx.detect_host(fr[None])[0], want)
+        else:
+            ctx.detect_host(fr[None])
+    ctx.close()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 256 << 20, "workspace memory is not returned: %d MiB lost" % ((free0 - free1) >> 20)
