@@ -156,20 +156,26 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
     const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_step, int rows, int cols,
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
     uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
-    size_t pyr_stride, int R, int lds_pitch) {
-  extern __shared__ uint32_t rowbuf[];                 // [2][R][lds_pitch] row prefixes | [lds_pitch] x table
+    size_t pyr_stride, int R, int lds_pitch, int src_pitch) {
+  extern __shared__ uint32_t rowbuf[];   // [2][R][lds_pitch] row prefixes | [lds_pitch] x table | per wave 2 source rows
   uint32_t* rs = rowbuf;
   uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
   uint32_t* xt_s = rowbuf + (size_t)2 * R * lds_pitch;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the two source rows a destination row interpolates between are staged per wavefront with
+  // coalesced dword loads; the 4 bytes per pixel are then gathered from LDS instead of through
+  // the (much slower) per-lane byte path of the vector memory unit
+  uint8_t* sr0 = (uint8_t*)(xt_s + lds_pitch) + (size_t)wave * 2 * src_pitch;
+  uint8_t* sr1 = sr0 + src_pitch;
   const HC_CONST DevLevel& L = as_const(levels)[blockIdx.y];
   const int frame = blockIdx.x;
   const int w = L.w, h = L.h, pitch = L.int_pitch;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint8_t* src = frames + (size_t)frame * frame_stride;
   const uint32_t* yt_l = ytab + L.ytab_ofs;
   uint32_t* S = sum + (size_t)frame * int_stride + L.int_ofs;
   uint32_t* Q = sq ? sq + (size_t)frame * int_stride + L.int_ofs : nullptr;   // null: sum only (mask integral)
   uint8_t* P = pyr ? pyr + (size_t)frame * pyr_stride + L.pyr_ofs : nullptr;
+  const bool dwords = ((((size_t)src) | row_step) & 3) == 0;               // uniform: rows are 4-byte aligned
   uint32_t col_s[CMAX], col_q[CMAX];
 #pragma unroll
   for (int k = 0; k < CMAX; k++) col_s[k] = col_q[k] = 0;
@@ -183,11 +189,22 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       const uint32_t yt = yt_l[dy];
       const int oy = yt >> 9, oy1 = min(oy + 1, rows - 1);
       const uint32_t cy1 = yt & 511u, cy0 = 256u - cy1;
-      const uint8_t* r0 = src + (size_t)oy * row_step;
-      const uint8_t* r1 = src + (size_t)oy1 * row_step;
+      const uint8_t* g0 = src + (size_t)oy * row_step;
+      const uint8_t* g1 = src + (size_t)oy1 * row_step;
+      if (dwords) {
+        const int nd = (cols + 3) >> 2;                 // src_pitch is a multiple of 4 >= cols; row_step >= cols
+        for (int i = lane; i < nd; i += 64) {
+          ((uint32_t*)sr0)[i] = ((const uint32_t*)g0)[i];
+          ((uint32_t*)sr1)[i] = ((const uint32_t*)g1)[i];
+        }
+      } else {
+        for (int i = lane; i < cols; i += 64) { sr0[i] = g0[i]; sr1[i] = g1[i]; }
+      }
+      // the same wavefront wrote and now reads the staging rows: LDS operations of one wave execute in
+      // order, only the compiler has to be kept from moving the reads up
+      __builtin_amdgcn_wave_barrier();
       uint32_t carry_s = 0, carry_q = 0;
       for (int x0 = 0; x0 < w; x0 += 64 * PI_UNROLL) {
-        // all source bytes of PI_UNROLL chunks are requested before the first scan consumes any
         uint32_t px[PI_UNROLL];
 #pragma unroll
         for (int u = 0; u < PI_UNROLL; u++) {
@@ -195,8 +212,8 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
           const uint32_t xt = xt_s[min(x, lds_pitch - 1)];
           const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
           const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
-          const uint32_t h0 = cx0 * r0[ox] + cx1 * r0[ox1];
-          const uint32_t h1 = cx0 * r1[ox] + cx1 * r1[ox1];
+          const uint32_t h0 = cx0 * sr0[ox] + cx1 * sr0[ox1];
+          const uint32_t h1 = cx0 * sr1[ox] + cx1 * sr1[ox1];
           px[u] = x < w ? min((h0 * cy0 + h1 * cy1 + 32768u) >> 16, 255u) : 0u;
         }
 #pragma unroll
@@ -579,13 +596,19 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
                             uint8_t* pyr, size_t pyr_stride) {
   if (nlevels == 0 || nframes == 0) return 0;
   const int lds_pitch = (max_w + 63) & ~63;
-  int R = PI_THREADS / 64;                       // rows per chunk: (2 R + 1) x pitch words of LDS, <= 64 KB (128 KB for 16 waves)
-  while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 > (PI_THREADS > 512 ? 131072u : 65536u)) R >>= 1;
-  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4;
+  const int src_pitch = (cols + 3 + 3) & ~3;     // staged source row: dword granular, >= cols
+  const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
+  int R = PI_THREADS / 64;                       // rows per chunk: (2 R + 1) x pitch words + staging rows of LDS
+  while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 + stage > 81920u) R >>= 1;      // 2 workgroups per CU
+  if (R < 4) {                                                                          // very wide frames: 1 per CU
+    R = PI_THREADS / 64;
+    while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 + stage > 147456u) R >>= 1;
+  }
+  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
 #define HC_PI(C)                                                                                                  \
   hipLaunchKernelGGL((k_pyramid_integral<C>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
-                     levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch)
+                     levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch)
   if (max_w <= 2 * PI_THREADS) HC_PI(2);
   else if (max_w <= 4 * PI_THREADS) HC_PI(4);
   else if (max_w <= 8 * PI_THREADS) HC_PI(8);
