@@ -523,3 +523,20 @@ def test_context_lifecycle_soak(pkg, oracle, synth):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 256 << 20, "workspace memory is not returned: %d MiB lost" % ((free0 - free1) >> 20)
+
+
+def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path):
+    """The batched C ABI from plain C++ (hip_cascade/throughput_demo.cpp): pipelined host-frame batches;
+    deterministic box count equal to the oracle's."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "throughput_demo")
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(i), nfaces=3, min_size=40, max_size=110)[0]
+                       for i in range(10)])
+    f = tmp_path / "frames.u8"
+    frames.tofile(f)
+    r = subprocess.run([demo, oracle.cascade_path("alt"), str(f), "10", "240", "320", "4", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    oc = oracle.OracleCascade(oracle.cascade_path("alt"))
+    want = sum(len(oc.detect(fr, 1.1, 2, (30, 30))[0]) for fr in frames)
+    assert ("%d boxes per pass" % want) in r.stdout, r.stdout

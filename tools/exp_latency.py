@@ -1,0 +1,22 @@
+"""Single-frame latency of the synchronous drop-in call (hc_detect_multiscale / hc_detect_faces)."""
+import sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np
+import bench, importlib
+pkg = bench.load_package(); synth = importlib.import_module("ugproj_detector_amd.synth")
+import oracle_lib
+casc = pkg.Cascade(oracle_lib.cascade_path("alt"))
+for (rows, cols) in [(360, 640), (720, 1280), (1080, 1920)]:
+    fr = synth.planted(rows, cols, synth.frame_seed(0))[0]
+    casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30))
+    t = []
+    for i in range(30):
+        t0 = time.perf_counter(); r = casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30)); t.append(time.perf_counter() - t0)
+    print("detectMultiScale %dx%d: median %.3f ms, min %.3f ms, %d boxes" % (cols, rows, 1e3 * np.median(t), 1e3 * min(t), len(r)))
+bgr = synth.planted_bgr(360, 640, synth.frame_seed(0))[0]
+casc.detect_faces(bgr)
+t = []
+for i in range(30):
+    t0 = time.perf_counter(); r = casc.detect_faces(bgr); t.append(time.perf_counter() - t0)
+print("detectFaces 640x360 BGR: median %.3f ms, min %.3f ms, %d boxes" % (1e3 * np.median(t), 1e3 * min(t), len(r)))
