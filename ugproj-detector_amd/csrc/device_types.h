@@ -36,6 +36,25 @@ struct TileGeom {
   int32_t cols;    // integral columns staged
 };
 
+// Corner-sharing kind of a stump.  Haar features are nested rects, so corners of rect 1 / rect 2
+// often coincide with corners already loaded for rect 0 / rect 1; six patterns cover every shared
+// corner in the four reference cascades.  Inside a stage whose f64 leaf sum is exact in any order
+// (DevStage::exact) the host groups the stumps by kind, and the device runs one straight-line loop
+// per kind that reads each distinct corner once (7.5 instead of 8.7 LDS reads per stump).
+enum NodeKind : int32_t {
+  NK_NONE2 = 0,     // 2 rects, 8 reads (also the safe default for any 2-rect pattern not listed)
+  NK_BOTTOM = 1,    // 2 rects: r1.c2 == r0.c2, r1.c3 == r0.c3            6 reads
+  NK_RIGHT = 2,     // 2 rects: r1.c1 == r0.c1, r1.c3 == r0.c3            6 reads
+  NK_LEFT = 3,      // 2 rects: r1.c0 == r0.c0, r1.c2 == r0.c2            6 reads
+  NK_TOP = 4,       // 2 rects: r1.c0 == r0.c0, r1.c1 == r0.c1            6 reads
+  NK_ANTIDIAG = 5,  // 3 rects: r1.c1 == r0.c1, r2.c1 == r1.c2, r2.c2 == r0.c2   9 reads
+  NK_DIAG = 6,      // 3 rects: r1.c0 == r0.c0, r2.c0 == r1.c3, r2.c3 == r0.c3   9 reads
+  NK_NONE3 = 7,     // 3 rects, 12 reads
+  NK_COUNT = 8
+};
+// end[k] = index (relative to DevStage::first) one past the last stump of kind k; end[-1] = 0
+struct DevStageKinds { uint16_t end[NK_COUNT]; };
+
 // One weak-classifier node, offsets pre-resolved for a TileGeom.
 struct DevNode {
   uint16_t off[12];   // LDS word offsets of 3 rects x 4 corners relative to the window origin word

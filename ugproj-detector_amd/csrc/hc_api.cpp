@@ -157,6 +157,7 @@ struct hc_context {
                *d_band_items[2] = {nullptr, nullptr};
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
   hc::DevStage* d_stages = nullptr;
+  hc::DevStageKinds* d_kinds = nullptr;
   hc::DevTree* d_trees = nullptr;
   float* d_leaves = nullptr;
   unsigned long long* d_cand = nullptr;
@@ -261,6 +262,23 @@ void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vect
   }
 }
 
+// corner-sharing kind of a stump (device_types.h NodeKind): compares corner coordinates
+int node_kind(const hc::ModelNode& n) {
+  auto cx = [&](int r, int k) { return n.rect[r][0] + ((k & 1) ? n.rect[r][2] : 0); };
+  auto cy = [&](int r, int k) { return n.rect[r][1] + ((k & 2) ? n.rect[r][3] : 0); };
+  auto same = [&](int r1, int k1, int r2, int k2) { return cx(r1, k1) == cx(r2, k2) && cy(r1, k1) == cy(r2, k2); };
+  if (n.weight[2] == 0.f) {
+    if (same(1, 2, 0, 2) && same(1, 3, 0, 3)) return hc::NK_BOTTOM;
+    if (same(1, 1, 0, 1) && same(1, 3, 0, 3)) return hc::NK_RIGHT;
+    if (same(1, 0, 0, 0) && same(1, 2, 0, 2)) return hc::NK_LEFT;
+    if (same(1, 0, 0, 0) && same(1, 1, 0, 1)) return hc::NK_TOP;
+    return hc::NK_NONE2;
+  }
+  if (same(1, 1, 0, 1) && same(2, 1, 1, 2) && same(2, 2, 0, 2)) return hc::NK_ANTIDIAG;
+  if (same(1, 0, 0, 0) && same(2, 0, 1, 3) && same(2, 3, 0, 3)) return hc::NK_DIAG;
+  return hc::NK_NONE3;
+}
+
 // True when every partial sum of the stage's leaf values, in any order, is exactly
 // representable in f64: all leaves are integer multiples of q = 2^emin and sum |leaf| / q < 2^53.
 // The sequential f64 accumulation of upstream then equals the mathematical sum,
@@ -302,6 +320,7 @@ int upload_model(hc_context* c) {
   }
   std::vector<hc::DevStage> st;
   std::vector<hc::DevTree> tr;
+  std::vector<hc::DevStageKinds> kinds;
   for (const hc::ModelStage& s : m.stages) {
     hc::DevStage d{};
     d.first = m.is_stump() ? m.trees[s.first_tree].first_node : s.first_tree;
@@ -309,12 +328,37 @@ int upload_model(hc_context* c) {
     d.thr = s.thr;
     d.exact = stage_sum_is_exact(m, s) ? 1 : 0;
     st.push_back(d);
+    if (m.is_stump()) {
+      // Stumps of a stage may be regrouped by kind only when the stage's f64 sum is exact in any order
+      // (d.exact).  Any other stage keeps file order and is evaluated by the ordered generic path on the
+      // device (its end[] stays zero and is never read).
+      hc::DevStageKinds kd{};
+      if (s.ntrees > 65535) return set_err(HC_ERR_UNSUPPORTED, "stage too long");
+      if (d.exact) {
+        std::vector<int> order(s.ntrees);
+        for (int i = 0; i < s.ntrees; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+          return node_kind(m.nodes[d.first + x]) < node_kind(m.nodes[d.first + y]);
+        });
+        for (int g = 0; g < 2; g++) {
+          std::vector<hc::DevNode> tmp(s.ntrees);
+          for (int i = 0; i < s.ntrees; i++) tmp[i] = nd[g][d.first + order[i]];
+          std::copy(tmp.begin(), tmp.end(), nd[g].begin() + d.first);
+        }
+        int cnt[hc::NK_COUNT] = {0};
+        for (int i = 0; i < s.ntrees; i++) cnt[node_kind(m.nodes[d.first + i])]++;
+        int acc = 0;
+        for (int k2 = 0; k2 < hc::NK_COUNT; k2++) { acc += cnt[k2]; kd.end[k2] = (uint16_t)acc; }
+      }
+      kinds.push_back(kd);
+    }
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   int rc;
   if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;
   if ((rc = dev_upload(&c->d_nodes[1], nd[1]))) return rc;
   if ((rc = dev_upload(&c->d_stages, st))) return rc;
+  if (m.is_stump() && (rc = dev_upload(&c->d_kinds, kinds))) return rc;
   if ((rc = dev_upload(&c->d_trees, tr))) return rc;
   if ((rc = dev_upload(&c->d_leaves, m.leaves))) return rc;
   return HC_OK;
@@ -371,7 +415,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
       A.levels = c->d_levels; A.bands = c->d_band_items[k]; A.nbands = (int)P.band_items[k].size();
-      A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.nstages = (int)m.stages.size();
+      A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
       if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
       A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
       A.sparse_max = c->sparse_max;
@@ -510,7 +554,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   ctx->free_workspace();
-  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves};
+  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_kinds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

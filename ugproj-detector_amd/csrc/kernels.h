@@ -20,6 +20,7 @@ struct CascadeArgs {
   int nbands;
   const DevNode* nodes;       // corner offsets resolved for g
   const DevStage* stages;
+  const DevStageKinds* kinds;  // per stage: stumps grouped by NodeKind (null for tree cascades)
   int nstages;
   const DevTree* trees;
   const float* leaves;

@@ -358,6 +358,70 @@ __device__ __forceinline__ bool stage_passes(const int32_t* tile, int base, floa
   return !(acc < (double)sthr);
 }
 
+// ---- stump stages with the stumps grouped by corner-sharing kind (device_types.h NodeKind) ----
+template <int KIND>
+__device__ __forceinline__ float feature_value_kind(const int32_t* tile, int base, const NodeRegs& n, float vnf) {
+  const int a0 = tile[base + HC_OFF(n.q0, 0)], a1 = tile[base + HC_OFF(n.q0, 1)];
+  const int a2 = tile[base + HC_OFF(n.q0, 2)], a3 = tile[base + HC_OFF(n.q0, 3)];
+  const int b0 = (KIND == NK_LEFT || KIND == NK_TOP || KIND == NK_DIAG) ? a0 : tile[base + HC_OFF(n.q0, 4)];
+  const int b1 = (KIND == NK_RIGHT || KIND == NK_TOP || KIND == NK_ANTIDIAG) ? a1 : tile[base + HC_OFF(n.q0, 5)];
+  const int b2 = (KIND == NK_BOTTOM || KIND == NK_LEFT) ? a2 : tile[base + HC_OFF(n.q0, 6)];
+  const int b3 = (KIND == NK_BOTTOM || KIND == NK_RIGHT) ? a3 : tile[base + HC_OFF(n.q0, 7)];
+  const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]);
+  float ret = w0 * (float)(a0 - a1 - a2 + a3) + w1 * (float)(b0 - b1 - b2 + b3);
+  if (KIND == NK_ANTIDIAG || KIND == NK_DIAG || KIND == NK_NONE3) {
+    const int c0 = KIND == NK_DIAG ? b3 : tile[base + HC_OFF(n.q1, 0)];
+    const int c1 = KIND == NK_ANTIDIAG ? b2 : tile[base + HC_OFF(n.q1, 1)];
+    const int c2 = KIND == NK_ANTIDIAG ? a2 : tile[base + HC_OFF(n.q1, 2)];
+    const int c3 = KIND == NK_DIAG ? a3 : tile[base + HC_OFF(n.q1, 3)];
+    ret += __uint_as_float(n.q2[0]) * (float)(c0 - c1 - c2 + c3);
+  }
+  return ret * vnf;
+}
+
+template <int KIND>
+__device__ __forceinline__ void stump_run(const int32_t* tile, int base, float vnf, const HC_CONST DevNode* nodes,
+                                          int first, int count, double& acc) {
+  if (count <= 0) return;                                     // wave-uniform
+  NodeRegs cur = load_node(nodes, first);
+  for (int t = 0; t < count; t++) {
+    const NodeRegs nxt = load_node(nodes, first + min(t + 1, count - 1));
+    const float v = feature_value_kind<KIND>(tile, base, cur, vnf);
+    const float thr = __uint_as_float(cur.q2[1]);
+    acc += (double)(v < thr ? __uint_as_float(cur.q2[2]) : __uint_as_float(cur.q2[3]));
+    cur = nxt;
+  }
+}
+
+__device__ __forceinline__ bool stage_passes_kinds(const int32_t* tile, int base, float vnf, const HC_CONST DevStage& st,
+                                                   const HC_CONST DevStageKinds& kd, const HC_CONST DevNode* nodes) {
+  double acc = 0.0;
+  const int first = st.first;
+  const float sthr = st.thr;
+  const int e0 = kd.end[0], e1 = kd.end[1], e2 = kd.end[2], e3 = kd.end[3], e4 = kd.end[4], e5 = kd.end[5],
+            e6 = kd.end[6], e7 = kd.end[7];
+  stump_run<NK_NONE2>(tile, base, vnf, nodes, first, e0, acc);
+  stump_run<NK_BOTTOM>(tile, base, vnf, nodes, first + e0, e1 - e0, acc);
+  stump_run<NK_RIGHT>(tile, base, vnf, nodes, first + e1, e2 - e1, acc);
+  stump_run<NK_LEFT>(tile, base, vnf, nodes, first + e2, e3 - e2, acc);
+  stump_run<NK_TOP>(tile, base, vnf, nodes, first + e3, e4 - e3, acc);
+  stump_run<NK_ANTIDIAG>(tile, base, vnf, nodes, first + e4, e5 - e4, acc);
+  stump_run<NK_DIAG>(tile, base, vnf, nodes, first + e5, e6 - e5, acc);
+  stump_run<NK_NONE3>(tile, base, vnf, nodes, first + e6, e7 - e6, acc);
+  return !(acc < (double)sthr);
+}
+
+// One stage for one window per lane: trees -> ordered tree walk; stump stage with an order-free
+// (exact) sum -> kind-grouped runs; any other stump stage -> ordered generic evaluation in file order.
+template <bool TREE>
+__device__ __forceinline__ bool eval_stage(const int32_t* tile, int base, float vnf, int s, const HC_CONST DevStage* stages,
+                                           const HC_CONST DevStageKinds* kinds, const HC_CONST DevNode* nodes,
+                                           const HC_CONST DevTree* trees, const float* __restrict__ leaves) {
+  if (TREE) return stage_passes<true>(tile, base, vnf, stages[s], nodes, trees, leaves);
+  if (stages[s].exact) return stage_passes_kinds(tile, base, vnf, stages[s], kinds[s], nodes);
+  return stage_passes<false>(tile, base, vnf, stages[s], nodes, trees, leaves);
+}
+
 // ---- sparse mode: ONE window per wavefront, the stage's weak classifiers spread over the
 // 64 lanes.  Legal only for stages whose f64 sum is exact in every order (DevStage::exact,
 // proven on the host from the leaf values): then the order-free wave reduction gives the very
@@ -436,6 +500,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
   const HC_CONST DevStage* stages = as_const(A.stages);
   const HC_CONST DevTree* trees = as_const(A.trees);
   const HC_CONST DevNode* nodes = as_const(A.nodes);
+  const HC_CONST DevStageKinds* kinds = as_const(A.kinds);
   const int frame = blockIdx.x;
   const int ys = L.ystep;
   const TileGeom G = A.g;
@@ -479,7 +544,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
       const bool evaluable = vnf > 0.f;
       const int base = rr * ys * G.pitch + lane;
       vnf_t[rr * TILE_POS + lane] = vnf;
-      const bool pass0 = stage_passes<TREE>(tile, base, vnf, stages[0], nodes, trees, A.leaves);
+      const bool pass0 = eval_stage<TREE>(tile, base, vnf, 0, stages, kinds, nodes, trees, A.leaves);
       const bool f = evaluable && !pass0;                      // "fails stage 0 if evaluated"
 
       // A.7 in closed form: position k is visited iff its distance to the nearest anchor
@@ -498,7 +563,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
       // and no queue traffic while most windows are still alive
       for (int s = 1; s < row_stages; s++) {
         if (!__any(surv)) break;
-        const bool ok = stage_passes<TREE>(tile, base, vnf, stages[s], nodes, trees, A.leaves);
+        const bool ok = eval_stage<TREE>(tile, base, vnf, s, stages, kinds, nodes, trees, A.leaves);
         if (A.taps && surv && !ok) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)s;
         surv = surv && ok;
       }
@@ -547,7 +612,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
           const int pos = active ? qin[i] : qin[0];
           const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
-          const bool ok = stage_passes<TREE>(tile, base, vnf_t[pos], stages[s], nodes, trees, A.leaves);
+          const bool ok = eval_stage<TREE>(tile, base, vnf_t[pos], s, stages, kinds, nodes, trees, A.leaves);
           const bool surv = active && ok;
           const unsigned long long sm = __ballot(surv);
           if (sm) {
