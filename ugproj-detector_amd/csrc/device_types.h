@@ -65,7 +65,8 @@ struct DevNode {
 static_assert(sizeof(DevNode) == 48, "DevNode layout");
 
 // first/count in nodes (stump) or trees (tree); exact != 0: the f64 sum of any subset of the
-// stage's leaf values is exact in any order (sparse stump-parallel mode is then bit-identical)
+// stage's leaf values is exact in any order (sparse stump-parallel mode is then bit-identical);
+// exact == 2: the same holds for every later stage as well
 struct DevStage { int32_t first, count; float thr; int32_t exact; };
 struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };
 

@@ -353,6 +353,12 @@ int upload_model(hc_context* c) {
       kinds.push_back(kd);
     }
   }
+  // exact == 2: this stage AND every later one have an order-free sum (the kernel may then finish a
+  // tile's last few windows without re-queuing them between stages)
+  for (int i = (int)st.size() - 1, all = 1; i >= 0; i--) {
+    all = all && st[i].exact;
+    if (all) st[i].exact = 2;
+  }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   int rc;
   if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;

@@ -592,7 +592,32 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
       if (threadIdx.x == 0) cnt[(t + 2) % 3] = 0;
       const int sfirst = stages[s].first, scount = stages[s].count;
       const float sthr = stages[s].thr;
-      if (n <= A.sparse_max && stages[s].exact) {
+      if (n <= A.sparse_max && stages[s].exact >= 2) {
+        // Few survivors and every remaining stage has an order-free sum (exact == 2): finish them
+        // here without any further queue or barrier.  Wave w takes windows w, w+4, ..; each window
+        // runs through all remaining stages one stage at a time, the stage's weak classifiers
+        // spread over the 64 lanes.
+        for (int i = wave; i < n; i += NW) {
+          const int pos = qin[i];
+          const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
+          const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
+          const float v = vnf_t[pos];
+          int ss = s;
+          for (; ss < A.nstages; ss++)
+            if (!stage_passes_sparse<TREE>(tile, base, v, stages[ss].first, stages[ss].count, stages[ss].thr, lane,
+                                           A.nodes, A.trees, A.leaves))
+              break;
+          if (lane == 0) {
+            if (ss == A.nstages) {                                // A.6c: raw candidate
+              const unsigned int slot = atomicAdd(A.cand_count, 1u);
+              if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)wy << 16) | (unsigned long long)wx;
+            }
+            if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)ss;
+          }
+        }
+        s = -1;                                                   // tile finished (uniform)
+        break;
+      } else if (n <= A.sparse_max && stages[s].exact) {
         // few survivors: one window per wavefront, lanes across the stage's weak classifiers
         for (int i = wave; i < n; i += NW) {
           const int pos = qin[i];
