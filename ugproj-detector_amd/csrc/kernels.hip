@@ -438,10 +438,21 @@ __device__ __forceinline__ float feature_value_lane(const int32_t* tile, int bas
   return ret * vnf;
 }
 
+// Sum of one f64 per lane over the wavefront, with DPP instead of LDS bpermutes: the inclusive-scan
+// pattern of wave_scan_u32 on the two halves of the double; lane 63 ends up with the total, which
+// is then broadcast.  Only used for stages whose sum is exact in any order, so the association
+// chosen here cannot change the result.
+#define HC_DPP_F64(v, CTRL, ROWMASK)                                                                   \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false),      \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false))
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v += HC_DPP_F64(v, 0x111, 0xF);   // row_shr:1  (lanes shifted in from outside the row read +0.0)
+  v += HC_DPP_F64(v, 0x112, 0xF);   // row_shr:2
+  v += HC_DPP_F64(v, 0x114, 0xF);   // row_shr:4
+  v += HC_DPP_F64(v, 0x118, 0xF);   // row_shr:8
+  v += HC_DPP_F64(v, 0x142, 0xA);   // row_bcast:15 -> rows 1,3
+  v += HC_DPP_F64(v, 0x143, 0xC);   // row_bcast:31 -> rows 2,3
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 template <bool TREE>
