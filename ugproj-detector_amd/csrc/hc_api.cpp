@@ -138,7 +138,7 @@ struct hc_context {
   hc::TileGeom geom[2] = {};
   size_t lds_bytes[2] = {0, 0};
   int tile_words[2] = {0, 0};
-  int sparse_max = 24;
+  int sparse_max = 32;
   bool fused_prep = true;   // k_pyramid_integral instead of k_resize + k_integral_rows + k_integral_cols
   int row_stages = 1;
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
