@@ -540,3 +540,26 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path):
     oc = oracle.OracleCascade(oracle.cascade_path("alt"))
     want = sum(len(oc.detect(fr, 1.1, 2, (30, 30))[0]) for fr in frames)
     assert ("%d boxes per pass" % want) in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("knobs", [
+    {"HC_BAND_ROWS1": "8", "HC_BAND_ROWS2": "16"},
+    {"HC_BAND_ROWS1": "32"},
+    {"HC_ROW_STAGES": "3", "HC_SPARSE_MAX": "0"},       # never sparse, three row-form stages
+    {"HC_SPARSE_MAX": "512"},                           # always sparse once a tile has survivors
+    {"HC_HOST_THREADS": "1", "HC_FUSED_PREP": "0"},
+])
+def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, knobs):
+    """Every tuning knob (read when a context is created) must leave all taps bit-exact."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    for name in ("alt", "alt2"):
+        path = oracle.cascade_path(name)
+        casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+        fr, _ = synth.planted(240, 320, synth.frame_seed(12), nfaces=3, min_size=40, max_size=110)
+        ctx = pkg.Context(casc)
+        ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), 1, 1 << 14)
+        ctx.enable_stage_taps(True)
+        got = ctx.detect_host(fr[None])
+        grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
+        assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
