@@ -134,7 +134,8 @@ struct hc_context {
   bool configured = false;
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
   // cascade-kernel tiling per ystep class (index 0: ystep 1, index 1: ystep 2)
-  int band_rows[2] = {16, 8};
+  int band_rows[2] = {16, 16};
+  int band_waves[2] = {4, 8};            // wavefronts per cascade workgroup (4 or 8); measured best on MI355X
   hc::TileGeom geom[2] = {};
   size_t lds_bytes[2] = {0, 0};
   int tile_words[2] = {0, 0};
@@ -429,7 +430,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.cand = c->d_cand; A.cand_count = c->d_count;
       A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
-      e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->lds_bytes[k], A);
+      e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k], c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
@@ -541,6 +542,8 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_BAND_ROWS1")) ctx->band_rows[0] = atoi(e_);
   if (const char* e_ = getenv("HC_BAND_ROWS2")) ctx->band_rows[1] = atoi(e_);
+  if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
+  if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0;
   for (int k = 0; k < 2; k++)
     if (ctx->band_rows[k] != 8 && ctx->band_rows[k] != 16 && ctx->band_rows[k] != 32) {

@@ -64,7 +64,8 @@ int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel
 int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride);
-// rows = band height in grid rows (8, 16 or 32); lds_bytes = tile + 2 queues + counters
-int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args);
+// rows = band height in grid rows (8, 16 or 32), nwaves = wavefronts per workgroup (4 or 8);
+// lds_bytes = tile + vnf + 2 queues + counters
+int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
 
 }  // namespace hc

@@ -492,10 +492,10 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
 #ifndef HC_CASCADE_WAVES
 #define HC_CASCADE_WAVES 8   // waves per SIMD the register allocator must leave room for
 #endif
-template <bool TREE, int ROWS>
-__global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(CascadeArgs A) {
+template <bool TREE, int ROWS, int NW>   // NW wavefronts per workgroup (4 or 8)
+__global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeArgs A) {
   constexpr int TILE_WIN = ROWS * TILE_POS;
-  constexpr int NW = WG_THREADS / 64;
+  constexpr int NTHREADS = NW * 64;
   extern __shared__ int32_t smem[];
   int32_t* tile = smem;
   float* vnf_t = (float*)(smem + A.tile_words);                 // variance factor of every window of the tile
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
           }
         }
       } else {
-        for (int i0 = wave * 64; i0 < n; i0 += WG_THREADS) {
+        for (int i0 = wave * 64; i0 < n; i0 += NTHREADS) {
           const int i = i0 + lane;
           const bool active = i < n;
           const int pos = active ? qin[i] : qin[0];
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(WG_THREADS, HC_CASCADE_WAVES) void k_cascade(Cascad
       const int t = s - row_stages;
       const int n = cnt[t % 3];
       const uint16_t* qin = queue + (t & 1) * TILE_WIN;
-      for (int i = threadIdx.x; i < n; i += WG_THREADS) {       // A.6c: raw candidates
+      for (int i = threadIdx.x; i < n; i += NTHREADS) {       // A.6c: raw candidates
         const int pos = qin[i];
         const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
         const unsigned int slot = atomicAdd(A.cand_count, 1u);
@@ -749,22 +749,33 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
 }
 
 template <bool TREE>
-static int launch_cascade_rows(hipStream_t st, int nframes, int rows, size_t lds_bytes, const CascadeArgs& args) {
-  const dim3 grid(nframes, args.nbands), block(WG_THREADS);
-  switch (rows) {
-    case 8: hipLaunchKernelGGL((k_cascade<TREE, 8>), grid, block, lds_bytes, st, args); break;
-    case 16: hipLaunchKernelGGL((k_cascade<TREE, 16>), grid, block, lds_bytes, st, args); break;
-    case 32: hipLaunchKernelGGL((k_cascade<TREE, 32>), grid, block, lds_bytes, st, args); break;
-    default: return (int)hipErrorInvalidValue;
+static int launch_cascade_rows(hipStream_t st, int nframes, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
+  const dim3 grid(nframes, args.nbands), block(nwaves * 64);
+  if (nwaves == 4) {
+    switch (rows) {
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 4>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 4>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 4>), grid, block, lds_bytes, st, args); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+  } else if (nwaves == 8) {
+    switch (rows) {
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 8>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 8>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 8>), grid, block, lds_bytes, st, args); break;
+      default: return (int)hipErrorInvalidValue;
+    }
+  } else {
+    return (int)hipErrorInvalidValue;
   }
   HC_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, size_t lds_bytes, const CascadeArgs& args) {
+int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
   if (args.nbands == 0 || nframes == 0) return 0;
-  return tree ? launch_cascade_rows<true>(st, nframes, rows, lds_bytes, args)
-              : launch_cascade_rows<false>(st, nframes, rows, lds_bytes, args);
+  return tree ? launch_cascade_rows<true>(st, nframes, rows, nwaves, lds_bytes, args)
+              : launch_cascade_rows<false>(st, nframes, rows, nwaves, lds_bytes, args);
 }
 
 }  // namespace hc
