@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
       hc::Plan p;
       if (hc::build_plan(m, s[0], s[1], 1.1, 30, 30, 0, 0, 16, 8, p) != 0) return 2;
       size_t words = 0;
-      for (const auto& L : p.levels) words += (size_t)L.int_pitch * (L.h + 1);
+      for (const auto& L : p.levels) words += (size_t)L.int_pitch * (L.h + 1) + 32;
       if ((int64_t)words != p.int_words) return 3;
     }
     // oracle end to end on a small noisy frame with a bright square

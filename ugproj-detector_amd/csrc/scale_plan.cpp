@@ -96,15 +96,18 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
     L.szw_h = std::max(L.h + 1 - m.win_h, 0);
     L.win_w = rne((float)m.win_w * sc);
     L.win_h = rne((float)m.win_h * sc);
-    L.int_pitch = (int)align_up(L.w + 1, 16);
+    // Column 0 of an integral is the zero column, so the stores of the integral kernels start at
+    // column 1.  A left pad of 31 words puts column 1 of every row on a 128-byte boundary: a
+    // wavefront's 64-dword store then covers exactly two cache lines instead of straddling three.
+    L.int_pitch = (int)align_up(L.w + 1 + 31, 32);
     L.pyr_ofs = p.pyr_bytes;
-    L.int_ofs = p.int_words;
+    L.int_ofs = p.int_words + 31;
     L.xtab_ofs = (int)p.xtab.size();
     L.ytab_ofs = (int)p.ytab.size();
     build_resize_table(cols, L.w, p.xtab);
     build_resize_table(rows, L.h, p.ytab);
     p.pyr_bytes += align_up((int64_t)L.w * L.h, 64);
-    p.int_words += (int64_t)L.int_pitch * (L.h + 1);
+    p.int_words += (int64_t)L.int_pitch * (L.h + 1) + 32;
     p.algorithmic_bytes += 16ll * (L.w + 1) * (L.h + 1);
     p.levels.push_back(L);
   }
