@@ -359,37 +359,61 @@ __device__ __forceinline__ bool stage_passes(const int32_t* tile, int base, floa
 }
 
 // ---- stump stages with the stumps grouped by corner-sharing kind (device_types.h NodeKind) ----
+// The distinct corners of one stump of kind KIND, read from the LDS tile (6, 8, 9 or 12 values).
 template <int KIND>
-__device__ __forceinline__ float feature_value_kind(const int32_t* tile, int base, const NodeRegs& n, float vnf) {
-  const int a0 = tile[base + HC_OFF(n.q0, 0)], a1 = tile[base + HC_OFF(n.q0, 1)];
-  const int a2 = tile[base + HC_OFF(n.q0, 2)], a3 = tile[base + HC_OFF(n.q0, 3)];
-  const int b0 = (KIND == NK_LEFT || KIND == NK_TOP || KIND == NK_DIAG) ? a0 : tile[base + HC_OFF(n.q0, 4)];
-  const int b1 = (KIND == NK_RIGHT || KIND == NK_TOP || KIND == NK_ANTIDIAG) ? a1 : tile[base + HC_OFF(n.q0, 5)];
-  const int b2 = (KIND == NK_BOTTOM || KIND == NK_LEFT) ? a2 : tile[base + HC_OFF(n.q0, 6)];
-  const int b3 = (KIND == NK_BOTTOM || KIND == NK_RIGHT) ? a3 : tile[base + HC_OFF(n.q0, 7)];
-  const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]);
-  float ret = w0 * (float)(a0 - a1 - a2 + a3) + w1 * (float)(b0 - b1 - b2 + b3);
+struct Corners { int a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3; };
+
+template <int KIND>
+__device__ __forceinline__ Corners<KIND> read_corners(const int32_t* tile, int base, const NodeRegs& n) {
+  Corners<KIND> c;
+  c.a0 = tile[base + HC_OFF(n.q0, 0)]; c.a1 = tile[base + HC_OFF(n.q0, 1)];
+  c.a2 = tile[base + HC_OFF(n.q0, 2)]; c.a3 = tile[base + HC_OFF(n.q0, 3)];
+  c.b0 = (KIND == NK_LEFT || KIND == NK_TOP || KIND == NK_DIAG) ? c.a0 : tile[base + HC_OFF(n.q0, 4)];
+  c.b1 = (KIND == NK_RIGHT || KIND == NK_TOP || KIND == NK_ANTIDIAG) ? c.a1 : tile[base + HC_OFF(n.q0, 5)];
+  c.b2 = (KIND == NK_BOTTOM || KIND == NK_LEFT) ? c.a2 : tile[base + HC_OFF(n.q0, 6)];
+  c.b3 = (KIND == NK_BOTTOM || KIND == NK_RIGHT) ? c.a3 : tile[base + HC_OFF(n.q0, 7)];
   if (KIND == NK_ANTIDIAG || KIND == NK_DIAG || KIND == NK_NONE3) {
-    const int c0 = KIND == NK_DIAG ? b3 : tile[base + HC_OFF(n.q1, 0)];
-    const int c1 = KIND == NK_ANTIDIAG ? b2 : tile[base + HC_OFF(n.q1, 1)];
-    const int c2 = KIND == NK_ANTIDIAG ? a2 : tile[base + HC_OFF(n.q1, 2)];
-    const int c3 = KIND == NK_DIAG ? a3 : tile[base + HC_OFF(n.q1, 3)];
-    ret += __uint_as_float(n.q2[0]) * (float)(c0 - c1 - c2 + c3);
+    c.c0 = KIND == NK_DIAG ? c.b3 : tile[base + HC_OFF(n.q1, 0)];
+    c.c1 = KIND == NK_ANTIDIAG ? c.b2 : tile[base + HC_OFF(n.q1, 1)];
+    c.c2 = KIND == NK_ANTIDIAG ? c.a2 : tile[base + HC_OFF(n.q1, 2)];
+    c.c3 = KIND == NK_DIAG ? c.a3 : tile[base + HC_OFF(n.q1, 3)];
+  } else {
+    c.c0 = c.c1 = c.c2 = c.c3 = 0;
   }
+  return c;
+}
+
+template <int KIND>
+__device__ __forceinline__ float feature_from_corners(const Corners<KIND>& c, const NodeRegs& n, float vnf) {
+  const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]);
+  float ret = w0 * (float)(c.a0 - c.a1 - c.a2 + c.a3) + w1 * (float)(c.b0 - c.b1 - c.b2 + c.b3);
+  if (KIND == NK_ANTIDIAG || KIND == NK_DIAG || KIND == NK_NONE3)
+    ret += __uint_as_float(n.q2[0]) * (float)(c.c0 - c.c1 - c.c2 + c.c3);
   return ret * vnf;
+}
+
+__device__ __forceinline__ double stump_leaf(const NodeRegs& n, float v) {
+  return (double)(v < __uint_as_float(n.q2[1]) ? __uint_as_float(n.q2[2]) : __uint_as_float(n.q2[3]));
 }
 
 template <int KIND>
 __device__ __forceinline__ void stump_run(const int32_t* tile, int base, float vnf, const HC_CONST DevNode* nodes,
                                           int first, int count, double& acc) {
-  if (count <= 0) return;                                     // wave-uniform
-  NodeRegs cur = load_node(nodes, first);
-  for (int t = 0; t < count; t++) {
-    const NodeRegs nxt = load_node(nodes, first + min(t + 1, count - 1));
-    const float v = feature_value_kind<KIND>(tile, base, cur, vnf);
-    const float thr = __uint_as_float(cur.q2[1]);
-    acc += (double)(v < thr ? __uint_as_float(cur.q2[2]) : __uint_as_float(cur.q2[3]));
-    cur = nxt;
+  // Two stumps per iteration: both nodes arrive in one scalar load and the LDS reads of both are issued
+  // before either feature is computed, so a wavefront pays the SMEM and the LDS latency once per pair.
+  int t = 0;
+  for (; t + 2 <= count; t += 2) {                            // wave-uniform trip count
+    const NodeRegs n0 = load_node(nodes, first + t), n1 = load_node(nodes, first + t + 1);
+    const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
+    const Corners<KIND> c1 = read_corners<KIND>(tile, base, n1);
+    __builtin_amdgcn_sched_barrier(0);                        // keep all reads ahead of the arithmetic
+    acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
+    acc += stump_leaf(n1, feature_from_corners<KIND>(c1, n1, vnf));
+  }
+  if (t < count) {
+    const NodeRegs n0 = load_node(nodes, first + t);
+    const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
+    acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
   }
 }
 
