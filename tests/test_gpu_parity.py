@@ -525,8 +525,10 @@ def test_context_lifecycle_soak(pkg, oracle, synth):
     assert free0 - free1 < 256 << 20, "workspace memory is not returned: %d MiB lost" % ((free0 - free1) >> 20)
 
 
-def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path):
-    """The batched C ABI from plain C++ (hip_cascade/throughput_demo.cpp): pipelined host-frame batches;
+@pytest.mark.parametrize("pool", ["pageable", "pinned", "registered"])
+def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
+    """The batched C ABI from plain C++ (hip_cascade/throughput_demo.cpp): pipelined host-frame batches from
+    pageable memory, from an hc_host_alloc pool and from a buffer pinned with hc_host_register;
     deterministic box count equal to the oracle's."""
     import os
     import subprocess
@@ -535,7 +537,8 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path):
                        for i in range(10)])
     f = tmp_path / "frames.u8"
     frames.tofile(f)
-    r = subprocess.run([demo, oracle.cascade_path("alt"), str(f), "10", "240", "320", "4", "3"], capture_output=True, text=True)
+    r = subprocess.run([demo, oracle.cascade_path("alt"), str(f), "10", "240", "320", "4", "3", pool],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout
     oc = oracle.OracleCascade(oracle.cascade_path("alt"))
     want = sum(len(oc.detect(fr, 1.1, 2, (30, 30))[0]) for fr in frames)

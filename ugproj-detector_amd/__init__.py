@@ -69,6 +69,10 @@ _SIGS = {
     "hc_context_destroy": (None, [C.c_void_p]),
     "hc_context_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
     "hc_detect_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
+    "hc_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "hc_host_free": (None, [C.c_void_p]),
+    "hc_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "hc_host_unregister": (C.c_int, [C.c_void_p]),
     "hc_detect_batch_enqueue_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "hc_detect_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hc_batch_raw_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

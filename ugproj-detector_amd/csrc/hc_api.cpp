@@ -635,10 +635,37 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
   const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
-  for (int f = 0; f < nframes; f++)
-    HIPCHK(hipMemcpy2DAsync(ctx->d_frames + (size_t)f * rows * cols, cols, h_frames + (size_t)f * frame_stride_bytes,
-                            row_step_bytes, cols, rows, hipMemcpyHostToDevice, ctx->stream));
+  if (row_step_bytes == cols && (nframes == 1 || frame_stride_bytes == rows * cols)) {
+    HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, (size_t)nframes * rows * cols, hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    for (int f = 0; f < nframes; f++)
+      HIPCHK(hipMemcpy2DAsync(ctx->d_frames + (size_t)f * rows * cols, cols, h_frames + (size_t)f * frame_stride_bytes,
+                              row_step_bytes, cols, rows, hipMemcpyHostToDevice, ctx->stream));
+  }
   return enqueue_device(ctx, ctx->d_frames, rows * cols, cols, nframes);
+}
+
+int hc_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) return set_err(HC_ERR_ARG, "hc_host_alloc: bad arguments");
+  *out = nullptr;
+  HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return HC_OK;
+}
+
+void hc_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int hc_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0) return set_err(HC_ERR_ARG, "hc_host_register: bad arguments");
+  HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+  return HC_OK;
+}
+
+int hc_host_unregister(void* p) {
+  if (!p) return set_err(HC_ERR_ARG, "hc_host_unregister: null pointer");
+  HIPCHK(hipHostUnregister(p));
+  return HC_OK;
 }
 
 }  // extern "C"

@@ -1,12 +1,16 @@
 // throughput_demo.cpp -- the batched C ABI driven from plain C++ (no Python, no torch, no HIP headers):
 // two contexts software-pipelined, frames handed over as HOST buffers (so the rate printed here is the
 // PCIe-inclusive one: H2D of every frame + kernels + D2H of candidates + host grouping).
-//   throughput_demo <cascade> <frames.u8> <nframes> <rows> <cols> [batch=32] [rounds=8]
+//   throughput_demo <cascade> <frames.u8> <nframes> <rows> <cols> [batch=32] [rounds=8] [pool=pageable|pinned|registered]
+// pool: where the frames live on the host -- plain pageable memory (what cv::VideoCapture hands the reference),
+// a page-locked pool from hc_host_alloc, or the pageable buffer pinned in place with hc_host_register.
 // frames.u8: nframes tight 8-bit gray frames.  Prints one line per round and a summary:
 //   frames/s, total boxes (identical every round: the path is deterministic).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/hip_cascade.h"
@@ -17,9 +21,22 @@ int main(int argc, char** argv) {
   if (argc < 6) { fprintf(stderr, "usage: %s cascade frames.u8 nframes rows cols [batch] [rounds]\n", argv[0]); return 64; }
   const int nframes = atoi(argv[3]), rows = atoi(argv[4]), cols = atoi(argv[5]);
   const int batch = argc > 6 ? atoi(argv[6]) : 32, rounds = argc > 7 ? atoi(argv[7]) : 8;
-  std::vector<unsigned char> frames((size_t)nframes * rows * cols);
+  const std::string pool = argc > 8 ? argv[8] : "pageable";
+  const size_t total_bytes = (size_t)nframes * rows * cols;
+  std::vector<unsigned char> pageable;
+  unsigned char* frames = nullptr;
+  if (pool == "pinned") {
+    void* p = nullptr;
+    CHECK(hc_host_alloc(total_bytes, &p));
+    frames = (unsigned char*)p;
+  } else {
+    pageable.resize(total_bytes);
+    frames = pageable.data();
+    if (pool == "registered") CHECK(hc_host_register(frames, total_bytes));
+    else if (pool != "pageable") { fprintf(stderr, "unknown pool %s\n", pool.c_str()); return 64; }
+  }
   FILE* f = fopen(argv[2], "rb");
-  if (!f || fread(frames.data(), 1, frames.size(), f) != frames.size()) { fprintf(stderr, "cannot read frames\n"); return 1; }
+  if (!f || fread(frames, 1, total_bytes, f) != total_bytes) { fprintf(stderr, "cannot read frames\n"); return 1; }
   fclose(f);
   hc_cascade* casc = nullptr;
   if (hc_cascade_load(argv[1], &casc) != HC_OK) { fprintf(stderr, "cannot load cascade: %s\n", hc_last_error()); return 1; }
@@ -35,7 +52,7 @@ int main(int argc, char** argv) {
   const size_t fbytes = (size_t)rows * cols;
   auto enqueue = [&](int b) {
     const int n = std::min(batch, nframes - b * batch);
-    return hc_detect_batch_enqueue_host(ctx[b & 1], frames.data() + (size_t)b * batch * fbytes, fbytes, cols, n);
+    return hc_detect_batch_enqueue_host(ctx[b & 1], frames + (size_t)b * batch * fbytes, fbytes, cols, n);
   };
   long first_total = -1;
   double best = 0;
@@ -54,8 +71,10 @@ int main(int argc, char** argv) {
     if (total != first_total) { fprintf(stderr, "non-deterministic box count\n"); return 3; }
     if (r > 0 && nframes / dt > best) best = nframes / dt;
   }
-  printf("best %.1f frames/s PCIe-inclusive, %ld boxes per pass\n", best, first_total);
+  printf("best %.1f frames/s PCIe-inclusive (%s host frames), %ld boxes per pass\n", best, pool.c_str(), first_total);
   for (auto& c : ctx) hc_context_destroy(c);
+  if (pool == "pinned") hc_host_free(frames);
+  else if (pool == "registered") CHECK(hc_host_unregister(frames));
   hc_cascade_free(casc);
   return 0;
 }
