@@ -657,10 +657,15 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       const float sthr = stages[s].thr;
       if (n <= A.sparse_max && stages[s].exact >= 2) {
         // Few survivors and every remaining stage has an order-free sum (exact == 2): finish them
-        // here without any further queue or barrier.  Wave w takes windows w, w+4, ..; each window
-        // runs through all remaining stages one stage at a time, the stage's weak classifiers
-        // spread over the 64 lanes.
-        for (int i = wave; i < n; i += NW) {
+        // here without any further queue or barrier.  Each wavefront pulls the next window off the list
+        // (the still unused output counter of this stage serves as the work index: windows live from one
+        // more stage to all of them, a static split leaves wavefronts idle behind the unlucky one); a window
+        // runs through all remaining stages one stage at a time, the stage's weak classifiers spread over
+        // the 64 lanes.
+        for (;;) {
+          // all 64 lanes add 1: the counter moves in steps of 64 per grab, any lane's ticket >> 6 is the index
+          const int i = __builtin_amdgcn_readfirstlane(atomicAdd(cout, 1)) >> 6;
+          if (i >= n) break;
           const int pos = qin[i];
           const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
