@@ -323,16 +323,17 @@ __device__ __forceinline__ float feature_value(const int32_t* tile, int base, co
 }
 
 #ifdef HC_PHASE
-__device__ unsigned long long hc_phase[8];
+__device__ unsigned long long hc_phase[10];
 static void dump_phase(hipStream_t st, int nwaves) {
   (void)hipStreamSynchronize(st);
-  unsigned long long h[8];
+  unsigned long long h[10];
   (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(hc_phase), sizeof(h));
-  unsigned long long z[8] = {0};
+  unsigned long long z[10] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(hc_phase), z, sizeof(z));
-  static const char* nm[8] = {"fill", "stage0", "barrier", "dense", "sparse_requeue", "sparse_finish", "emit", "total"};
+  static const char* nm[10] = {"fill_load_store", "stage0", "stage_barriers", "dense", "sparse_requeue", "sparse_finish", "emit", "total",
+                               "wait_prev_tile", "fill_barrier"};
   fprintf(stderr, "[phase nw=%d]", nwaves);
-  for (int k = 0; k < 8; k++) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[k] / (double)h[7]);
+  for (int k = 0; k < 10; k++) fprintf(stderr, " %s=%.1f%%", nm[k], 100.0 * (double)h[k] / (double)h[7]);
   fprintf(stderr, "\n");
 }
 #endif
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
   const int row_stages = min(A.row_stages, A.nstages);   // stages evaluated in row form before the first compaction
   unsigned int carry = 0xffffffffu;   // bit j: is position 0 of the next tile visited, for owned row wave + 4j
 #ifdef HC_PHASE
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tlast = __builtin_readcyclecounter();
   const unsigned long long tstart = tlast;
 #endif
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
   for (int gx0 = 0; gx0 < nx; gx0 += TILE_POS) {
     const int x0 = gx0 * ys;
     __syncthreads();              // everybody is done with the previous tile and its queues
+    PH_MARK(8);
     for (int r = wave; r < G.rows; r += NW) {
       const int sy = y0 + r;
       const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
@@ -591,8 +593,9 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       }
     }
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
-    __syncthreads();
     PH_MARK(0);
+    __syncthreads();
+    PH_MARK(9);
 
     // ---- stage 0 on every position; x-skip chain; survivors -> queue 0
 #pragma unroll
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
 #ifdef HC_PHASE
   if (lane == 0) {
     ph[7] = __builtin_readcyclecounter() - tstart;
-    for (int k = 0; k < 8; k++) atomicAdd(&hc_phase[k], ph[k]);
+    for (int k = 0; k < 10; k++) atomicAdd(&hc_phase[k], ph[k]);
   }
 #endif
 }
