@@ -551,6 +551,8 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_ROW_STAGES": "3", "HC_SPARSE_MAX": "0"},       # never sparse, three row-form stages
     {"HC_SPARSE_MAX": "512"},                           # always sparse once a tile has survivors
     {"HC_HOST_THREADS": "1", "HC_FUSED_PREP": "0"},
+    {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
+    {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
 ])
 def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, knobs):
     """Every tuning knob (read when a context is created) must leave all taps bit-exact."""
