@@ -598,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
     PH_MARK(9);
 
     // ---- stage 0 on every position; x-skip chain; survivors -> queue 0
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < ROWS / NW; j++) {
       const int rr = wave + NW * j;
       const int gy = gy0 + rr, gx = gx0 + lane;
