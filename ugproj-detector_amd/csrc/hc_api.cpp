@@ -429,6 +429,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.row_stages = c->row_stages;
       A.cand = c->d_cand; A.cand_count = c->d_count;
       A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
+      if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
       e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k], c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
                                            A.nodes, A.trees, A.leaves))
               break;
           if (lane == 0) {
-            if (ss == A.nstages) {                                // A.6c: raw candidate
+            if (ss == A.nstages && A.cand_cap) {                  // A.6c: raw candidate (cap 0: truncated-cascade timing runs)
               const unsigned int slot = atomicAdd(A.cand_count, 1u);
               if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)wy << 16) | (unsigned long long)wx;
             }
@@ -733,8 +733,10 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       for (int i = threadIdx.x; i < n; i += NTHREADS) {       // A.6c: raw candidates
         const int pos = qin[i];
         const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
-        const unsigned int slot = atomicAdd(A.cand_count, 1u);
-        if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+        if (A.cand_cap) {
+          const unsigned int slot = atomicAdd(A.cand_count, 1u);
+          if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+        }
         if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
       }
     }
