@@ -312,7 +312,7 @@ int upload_model(hc_context* c) {
   for (int k = 0; k < 2; k++) {
     const int ystep = k + 1;
     c->geom[k] = make_geom(m, ystep, c->band_rows[k]);
-    const size_t words = (size_t)c->geom[k].pitch * c->geom[k].rows;
+    const size_t words = ((size_t)c->geom[k].pitch * c->geom[k].rows + 1) & ~(size_t)1;   // even: 8-byte aligned LDS regions behind the tile
     if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
     c->tile_words[k] = (int)words;
     // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | 2 queues x band_rows*64 u16 | 3 counters (+pad)

@@ -451,6 +451,28 @@ __device__ __forceinline__ bool stage_passes_kinds(const int32_t* tile, int base
   return !(acc < (double)sthr);
 }
 
+// Sum of the leaves of stumps [lo, hi) of a kind-grouped (exact) stage, in kind-sorted order: the share of one
+// wavefront when several wavefronts split a stage between them (k_cascade, cooperative mode).
+__device__ __forceinline__ double stage_partial_kinds(const int32_t* tile, int base, float vnf, const HC_CONST DevStage& st,
+                                                      const HC_CONST DevStageKinds& kd, const HC_CONST DevNode* nodes,
+                                                      int lo, int hi) {
+  double acc = 0.0;
+  const int first = st.first;
+  const int e0 = kd.end[0], e1 = kd.end[1], e2 = kd.end[2], e3 = kd.end[3], e4 = kd.end[4], e5 = kd.end[5],
+            e6 = kd.end[6], e7 = kd.end[7];
+#define HC_RUN(KIND, A_, B_) { const int a_ = max(A_, lo), b_ = min(B_, hi); stump_run<KIND>(tile, base, vnf, nodes, first + a_, b_ - a_, acc); }
+  HC_RUN(NK_NONE2, 0, e0)
+  HC_RUN(NK_BOTTOM, e0, e1)
+  HC_RUN(NK_RIGHT, e1, e2)
+  HC_RUN(NK_LEFT, e2, e3)
+  HC_RUN(NK_TOP, e3, e4)
+  HC_RUN(NK_ANTIDIAG, e4, e5)
+  HC_RUN(NK_DIAG, e5, e6)
+  HC_RUN(NK_NONE3, e6, e7)
+#undef HC_RUN
+  return acc;
+}
+
 // One stage for one window per lane: trees -> ordered tree walk; stump stage with an order-free
 // (exact) sum -> kind-grouped runs; any other stump stage -> ordered generic evaluation in file order.
 template <bool TREE>
@@ -701,6 +723,51 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
             else if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
           }
+        }
+      } else if (!TREE && ROWS >= 16 && stages[s].exact && ((n + 63) >> 6) * 2 <= NW) {
+        // Cooperative mode: the survivors fill at most NW/2 wavefronts, so the stage's critical path -- every
+        // stump in sequence on one wavefront while the others wait at the barrier -- is cut by giving each
+        // 64-window chunk to k = 2 or 4 wavefronts that evaluate 1/k of the stumps each.  Partial sums meet
+        // in LDS (the unused tails of the two queues); legal because the stage's f64 sum is order-free.
+        const int chunks = (n + 63) >> 6;
+        const int k = chunks * 4 <= NW && chunks <= 2 ? 4 : 2;
+        const int chunk = wave / k, slice = wave - chunk * k;
+        // scratch slot q = chunk * (k - 1) + slice - 1 (at most 6 of 64 doubles): three behind the first 256
+        // entries of each queue (chunks <= 4, so neither queue holds more than 256 entries in this stage;
+        // ROWS >= 16 makes a queue 2 KB; the host keeps tile_words even, so the doubles are 8-byte aligned)
+        double* const scr0 = (double*)(queue + 256);
+        double* const scr1 = (double*)(queue + TILE_WIN + 256);
+        const int i = chunk * 64 + lane;
+        const bool active = chunk < chunks && i < n;
+        const int pos = active ? qin[i] : qin[0];
+        const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
+        double part = 0.0;
+        if (chunk < chunks) {                                     // wave-uniform
+          part = stage_partial_kinds(tile, base, vnf_t[pos], stages[s], kinds[s], nodes, scount * slice / k,
+                                     scount * (slice + 1) / k);
+          if (slice) {
+            const int q = chunk * (k - 1) + slice - 1;
+            (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lane] = part;
+          }
+        }
+        PH_MARK(3);
+        __syncthreads();
+        PH_MARK(2);
+        if (chunk < chunks && slice == 0) {
+          for (int j = 1; j < k; j++) {
+            const int q = chunk * (k - 1) + j - 1;
+            part += (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lane];
+          }
+          const bool ok = !(part < (double)sthr);
+          const bool surv = active && ok;
+          const unsigned long long sm = __ballot(surv);
+          if (sm) {
+            int off = 0;
+            if (lane == 0) off = atomicAdd(cout, __popcll(sm));
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
+          }
+          if (A.taps && active && !ok) A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
         }
       } else {
         for (int i0 = wave * 64; i0 < n; i0 += NTHREADS) {
