@@ -19,3 +19,16 @@ t = []
 for i in range(30):
     t0 = time.perf_counter(); r = casc.detect_faces(bgr); t.append(time.perf_counter() - t0)
 print("detectFaces 640x360 BGR: median %.3f ms, min %.3f ms, %d boxes" % (1e3 * np.median(t), 1e3 * min(t), len(r)))
+
+# where a single 720p frame spends its time: per-kernel HIP-event times of a batch of one
+fr = synth.planted(720, 1280, synth.frame_seed(0))[0]
+ctx = pkg.Context(casc)
+ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), 1, 1 << 14)
+ctx.enable_timing(True)
+acc = None
+for i in range(12):
+    t0 = time.perf_counter(); ctx.detect_host(fr[None]); dt = time.perf_counter() - t0
+    ms = ctx.kernel_ms()
+    if i >= 2:
+        acc = dict(ms) if acc is None else {k: acc[k] + v for k, v in ms.items()}
+print("720p batch of 1: wall %.3f ms; kernels (ms): %s" % (1e3 * dt, {k: round(v / 10, 3) for k, v in acc.items()}))

@@ -191,7 +191,7 @@ struct hc_context {
   std::vector<hc_rect> last_raw;
   std::vector<int32_t> last_raw_ofs;
   std::unique_ptr<WorkerPool> pool;   // host post-processing workers (created on first multi-frame wait)
-  int host_threads = 8;
+  int host_threads = 4;   // 1 thread already hides the 64-frame grouping under the next batch (tools/exp_host_threads.sh)
 
   void free_workspace() {
     void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
