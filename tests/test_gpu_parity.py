@@ -10,6 +10,14 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _fused_prep_by_default(monkeypatch):
+    """Most tests here run batches of one frame, for which the library would pick the three parallel prep
+    kernels; pin the fused k_pyramid_integral (the throughput path) unless a test chooses otherwise.
+    test_unfused_prep_kernels_agree, the knob test and test_prep_policy_by_batch_size cover the other settings."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+
 CALL = dict(scale_factor=1.1, min_neighbors=2, min_size=(30, 30))      # reference detector.cc:25-31
 
 
@@ -350,6 +358,30 @@ def test_unfused_prep_kernels_agree(pkg, oracle, synth, monkeypatch):
     got = ctx.detect_host(fr[None])
     grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
     assert np.array_equal(got[0], grouped)
+
+
+def test_prep_policy_by_batch_size(pkg, oracle, synth, monkeypatch):
+    """Without HC_FUSED_PREP the context picks the prep kernels by batch size (parallel kernels up to 8
+    frames, fused k_pyramid_integral above): both give the oracle's boxes and identical integral words."""
+    monkeypatch.delenv("HC_FUSED_PREP", raising=False)
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted(180, 240, synth.frame_seed(20 + i), nfaces=2, min_size=40, max_size=80)[0]
+                       for i in range(12)])
+    want = [oc.detect(f, 1.1, 2, (30, 30))[0] for f in frames]
+    ctx = pkg.Context(casc)
+    ctx.configure(180, 240, 1.1, 2, (30, 30), (0, 0), max_batch=12, cand_capacity=1 << 14)
+    big = ctx.detect_host(frames)                      # 12 frames: fused
+    sum_big = ctx.read_tap(3, 0, pkg.TAP_SUM)
+    small = ctx.detect_host(frames[:4])                # 4 frames: parallel kernels
+    sum_small = ctx.read_tap(3, 0, pkg.TAP_SUM)
+    assert np.array_equal(sum_big, sum_small)
+    for i in range(12):
+        assert np.array_equal(oracle.sorted_boxes(big[i]), oracle.sorted_boxes(want[i]))
+    for i in range(4):
+        assert np.array_equal(small[i], big[i])
+    one = casc.detect_multiscale(frames[5], **CALL)    # the synchronous drop-in call: one frame
+    assert np.array_equal(one, big[5])
 
 
 def test_detect_faces_path(pkg, oracle, synth):
