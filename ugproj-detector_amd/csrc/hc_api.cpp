@@ -129,6 +129,9 @@ struct hc_context {
   bool own_stream = false;
   hipStream_t copy_stream = nullptr;   // D2H of results: never queues behind a later batch on `stream`
   hipEvent_t ev_done = nullptr;        // recorded on `stream` after the last kernel of a batch
+  hipStream_t side_stream = nullptr;   // small batches: the ystep-2 cascade launch runs beside the ystep-1 launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_max_batch = 2;              // ... up to this many frames (a full batch fills the chip with one launch)
 
   hc::Plan plan;
   bool configured = false;
@@ -422,6 +425,13 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
+    // With one or two frames neither cascade launch fills 256 CUs and a band walk is a serial chain of tiles:
+    // the two launches (independent: different levels) then run side by side on two streams.
+    const bool side = nframes <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
+    if (side) {
+      HIPCHK(hipEventRecord(c->ev_fork, s));
+      HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+    }
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
@@ -435,8 +445,13 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
-      e = hc::launch_cascade(s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k], c->lds_bytes[k], A);
+      e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k],
+                             c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    if (side) {
+      HIPCHK(hipEventRecord(c->ev_join, c->side_stream));
+      HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
   }
@@ -537,6 +552,9 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
   if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
     hc_context_destroy(ctx);
     return set_err(HC_ERR_HIP, "cannot create the result stream / event");
@@ -550,6 +568,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
+  if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   for (int k = 0; k < 2; k++)
     if (ctx->band_rows[k] != 8 && ctx->band_rows[k] != 16 && ctx->band_rows[k] != 32) {
       delete ctx;
@@ -566,7 +585,10 @@ void hc_context_destroy(hc_context* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+  if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   ctx->free_workspace();
   void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_kinds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
