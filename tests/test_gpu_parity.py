@@ -158,6 +158,32 @@ def test_noise_skip_chain(pkg, oracle, synth):
     _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (0, 0))
 
 
+@pytest.mark.parametrize("seg", [{"HC_SEG_MAX_BATCH": "0"}, {}, {"HC_SEG_TILES": "1"}, {"HC_SEG_TILES": "3"}])
+def test_row_long_stage0_failure_chains(pkg, oracle, synth, monkeypatch, seg):
+    """Horizontal stripes make EVERY window of a row evaluable and failing stage 0: the x-skip chain (A.7) then
+    runs unbroken from the row start, which is the worst case for the segmented band walk of small batches (a
+    segment must look back tile by tile to the row start to recover its skip state).  Left part stripes, right
+    part noise and a constant block, so that chains also end and restart inside rows.  All taps, whole bands
+    (HC_SEG_MAX_BATCH=0) and segments of 1, 2 (default) and 3 tiles."""
+    for k, v in seg.items():
+        monkeypatch.setenv(k, v)
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    H, W = 120, 900
+    y, x = np.mgrid[0:H, 0:W]
+    fr = np.where((y % 5) < 2, 228, 28).astype(np.uint8)                 # stripes: whole-row failure chains
+    fr[:, 600:] = synth.noise(H, W - 600, synth.frame_seed(31))          # chains break up in noise
+    fr[40:80, 300:420] = 128                                             # flat block: windows not evaluable
+    ctx = pkg.Context(casc)
+    ctx.configure(H, W, 1.1, 2, (0, 0), (0, 0), 1)
+    ctx.enable_stage_taps(True)
+    ctx.detect_host(fr[None])
+    _, _, taps = oc.detect(fr, 1.1, 2, (0, 0), (0, 0), want_taps=True)
+    runs = max(int(((t[r] == 0) | (t[r] == -2))[:128].all()) for t in taps[:3] for r in range(t.shape[0]))
+    assert runs == 1, "stimulus lost its long failure chains"
+    _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (0, 0))
+
+
 def test_scale_factor_and_size_limits(pkg, oracle, synth):
     path = oracle.cascade_path("alt2")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
@@ -583,6 +609,8 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_ROW_STAGES": "3", "HC_SPARSE_MAX": "0"},       # never sparse, three row-form stages
     {"HC_SPARSE_MAX": "512"},                           # always sparse once a tile has survivors
     {"HC_HOST_THREADS": "1", "HC_FUSED_PREP": "0"},
+    {"HC_SEG_MAX_BATCH": "0", "HC_SIDE_MAX_BATCH": "0"},  # small batches without band segments / side stream
+    {"HC_SEG_TILES": "1"},
     {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
     {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
 ])

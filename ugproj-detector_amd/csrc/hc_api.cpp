@@ -162,7 +162,9 @@ struct hc_context {
   uint32_t* d_xtab = nullptr;
   uint32_t* d_ytab = nullptr;
   hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
-               *d_band_items[2] = {nullptr, nullptr};
+               *d_band_items[2] = {nullptr, nullptr}, *d_seg_items[2] = {nullptr, nullptr};
+  int n_seg_items[2] = {0, 0};           // bands cut into segments of seg_tiles tiles: the work list of small batches
+  int seg_tiles = 2, seg_max_batch = 2;  // HC_SEG_TILES, HC_SEG_MAX_BATCH
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;
@@ -202,11 +204,13 @@ struct hc_context {
 
   void free_workspace() {
     void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
-                    d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_cand, d_count};
+                    d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_seg_items[0], d_seg_items[1], d_cand,
+                    d_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     d_frames = d_pyr = nullptr; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
     d_xtab = d_ytab = nullptr;
     d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items[0] = d_band_items[1] = nullptr;
+    d_seg_items[0] = d_seg_items[1] = nullptr;
     d_cand = nullptr; d_count = nullptr;
     if (h_cand) (void)hipHostFree(h_cand);
     if (h_count) (void)hipHostFree(h_count);
@@ -435,7 +439,10 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
-      A.levels = c->d_levels; A.bands = c->d_band_items[k]; A.nbands = (int)P.band_items[k].size();
+      const bool seg = nframes <= c->seg_max_batch && c->n_seg_items[k] > 0;
+      A.levels = c->d_levels;
+      A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
+      A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
       A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
       if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
       A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
@@ -569,6 +576,8 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
+  if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));
+  if (const char* e_ = getenv("HC_SEG_TILES")) ctx->seg_tiles = std::min(255, std::max(1, atoi(e_)));
   for (int k = 0; k < 2; k++)
     if (ctx->band_rows[k] != 8 && ctx->band_rows[k] != 16 && ctx->band_rows[k] != 32) {
       delete ctx;
@@ -636,6 +645,16 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   if ((rc = dev_upload(&ctx->d_var_items, P.var_items))) return rc;
   if ((rc = dev_upload(&ctx->d_band_items[0], P.band_items[0]))) return rc;
   if ((rc = dev_upload(&ctx->d_band_items[1], P.band_items[1]))) return rc;
+  for (int k = 0; k < 2; k++) {   // the same bands cut into x-segments (k_cascade re-derives the x-skip state per segment)
+    std::vector<hc::WorkItem> seg;
+    for (const hc::WorkItem& it : P.band_items[k]) {
+      const int ntiles = (P.levels[it.level].nx + hc::TILE_POS - 1) / hc::TILE_POS;
+      for (int t0 = 0; t0 < ntiles; t0 += ctx->seg_tiles)
+        seg.push_back(hc::WorkItem{it.level, it.a, (t0 * hc::TILE_POS) | (ctx->seg_tiles << 16)});
+    }
+    ctx->n_seg_items[k] = (int)seg.size();
+    if ((rc = dev_upload(&ctx->d_seg_items[k], seg))) return rc;
+  }
   HIPCHK(hipHostMalloc((void**)&ctx->h_cand, B * ctx->cand_per_frame * sizeof(unsigned long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
   ctx->pending = 0;

@@ -551,6 +551,24 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
 // lane k's corner reads are stride-1 in LDS).  Wave w owns grid rows w, w+4, .. of the band
 // for the whole walk, so the x-skip carry (A.7) stays in its registers.  Bigger ROWS = bigger
 // survivor pool per workgroup = fuller wavefronts in the middle stages, and less halo per window.
+// Stage the (G.rows x G.cols) window of the `sum` integral whose top-left corner is (x0, y0) into the LDS tile;
+// wave w loads rows w, w + NW, ..  Out-of-image entries read as 0 (only windows that are never evaluated use them).
+template <int NW>
+__device__ __forceinline__ void fill_tile(int32_t* tile, const uint32_t* __restrict__ I, const HC_CONST DevLevel& L,
+                                          const TileGeom& G, int ys, int x0, int y0, int wave, int lane) {
+  for (int r = wave; r < G.rows; r += NW) {
+    const int sy = y0 + r;
+    const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
+    int32_t* drow = tile + r * G.pitch;
+    for (int c = lane; c < G.cols; c += 64) {
+      const int sx = x0 + c;
+      const uint32_t v = (sy <= L.h && sx <= L.w) ? srow[sx] : 0u;
+      const int d = ys == 1 ? c : ((c & 1) * G.half + (c >> 1));
+      drow[d] = (int32_t)v;
+    }
+  }
+}
+
 #ifndef HC_CASCADE_WAVES
 #define HC_CASCADE_WAVES 8   // waves per SIMD the register allocator must leave room for
 #endif
@@ -599,21 +617,44 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
   const unsigned long long tstart = tlast;
 #endif
 
-  for (int gx0 = 0; gx0 < nx; gx0 += TILE_POS) {
+  // A work item is a whole band (b == 0) or a segment of it: b = first grid column | tiles << 16.  Segments let a
+  // small batch use the whole chip (a band walk is a serial chain of tiles); the only state a walk carries from
+  // tile to tile is the x-skip bit of every row (A.7), which a segment re-derives by looking back: it evaluates
+  // stage 0 on the tile to its left and applies the closed form below to position 63.  A row whose 64 positions
+  // there all fail stage 0 passes its incoming bit through unchanged (64 is even), so only such rows look one
+  // more tile to the left, down to the row start, whose bit is 1.
+  const int gx_begin = it.b & 0xffff;
+  const int gx_end = (it.b >> 16) ? min(nx, gx_begin + (it.b >> 16) * TILE_POS) : nx;
+  if (gx_begin > 0) {
+    unsigned int need = 0;
+    for (int j = 0; j < ROWS / NW; j++)
+      if (gy0 + wave + NW * j < ny) need |= 1u << j;
+    for (int gp = gx_begin - TILE_POS;; gp -= TILE_POS) {
+      if (!__syncthreads_or(need != 0 && gp >= 0)) break;       // uniform; also fences the previous tile
+      fill_tile<NW>(tile, I, L, G, ys, gp * ys, y0, wave, lane);
+      __syncthreads();
+#pragma unroll 1
+      for (int j = 0; j < ROWS / NW; j++) {
+        if (!((need >> j) & 1u)) continue;                        // wave-uniform
+        const int rr = wave + NW * j;
+        const float vnf = vnf_g[(size_t)(gy0 + rr) * nx + gp + lane];   // gp + 63 < gx_begin <= nx: all valid
+        const bool pass0 = eval_stage<TREE>(tile, rr * ys * G.pitch + lane, vnf, 0, stages, kinds, nodes, trees, A.leaves);
+        const unsigned long long fm = __ballot(vnf > 0.f && !pass0);
+        if (!(fm >> 63)) { need &= ~(1u << j); continue; }        // position 63 does not fail: next bit is 1
+        const unsigned long long below = ~fm & 0x7fffffffffffffffull;
+        if (!below) continue;                                     // all 64 fail: pass-through, look further left
+        const int anchor = 64 - __clzll((long long)below);
+        if (((63 - anchor) & 1) == 0) carry &= ~(1u << j);        // position 63 visited and failing: skip position 0
+        need &= ~(1u << j);
+      }
+    }
+  }
+
+  for (int gx0 = gx_begin; gx0 < gx_end; gx0 += TILE_POS) {
     const int x0 = gx0 * ys;
     __syncthreads();              // everybody is done with the previous tile and its queues
     PH_MARK(8);
-    for (int r = wave; r < G.rows; r += NW) {
-      const int sy = y0 + r;
-      const uint32_t* srow = I + (size_t)min(sy, L.h) * L.int_pitch;
-      int32_t* drow = tile + r * G.pitch;
-      for (int c = lane; c < G.cols; c += 64) {
-        const int sx = x0 + c;
-        const uint32_t v = (sy <= L.h && sx <= L.w) ? srow[sx] : 0u;
-        const int d = ys == 1 ? c : ((c & 1) * G.half + (c >> 1));
-        drow[d] = (int32_t)v;
-      }
-    }
+    fill_tile<NW>(tile, I, L, G, ys, x0, y0, wave, lane);
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
     PH_MARK(0);
     __syncthreads();
