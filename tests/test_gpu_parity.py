@@ -387,9 +387,11 @@ def test_unfused_prep_kernels_agree(pkg, oracle, synth, monkeypatch):
 
 
 def test_prep_policy_by_batch_size(pkg, oracle, synth, monkeypatch):
-    """Without HC_FUSED_PREP the context picks the prep kernels by batch size (parallel kernels up to 8
-    frames, fused k_pyramid_integral above): both give the oracle's boxes and identical integral words."""
+    """Without HC_FUSED_PREP the context picks the prep kernels by batch size (parallel kernels up to 16
+    720p-frame equivalents, fused k_pyramid_integral above; lowered here so that both sides are reached):
+    both give the oracle's boxes and identical integral words."""
     monkeypatch.delenv("HC_FUSED_PREP", raising=False)
+    monkeypatch.setenv("HC_FUSED_MIN_BATCH", "0.3")   # 12 frames of 180x240 = 0.56 equivalents: fused; 4 frames: not
     path = oracle.cascade_path("alt")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     frames = np.stack([synth.planted(180, 240, synth.frame_seed(20 + i), nfaces=2, min_size=40, max_size=80)[0]

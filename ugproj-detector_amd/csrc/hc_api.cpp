@@ -131,7 +131,7 @@ struct hc_context {
   hipEvent_t ev_done = nullptr;        // recorded on `stream` after the last kernel of a batch
   hipStream_t side_stream = nullptr;   // small batches: the ystep-2 cascade launch runs beside the ystep-1 launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int side_max_batch = 2;              // ... up to this many frames (a full batch fills the chip with one launch)
+  int side_max_batch = 8;              // ... up to this many frames (a full batch fills the chip with one launch)
 
   hc::Plan plan;
   bool configured = false;
@@ -147,7 +147,7 @@ struct hc_context {
   // k_resize + k_integral_rows + k_integral_cols (fully parallel: 0.07 instead of 0.39 ms for ONE 720p frame).
   // -1: by batch size (fused above fused_min_batch frames), 0: never fused, 1: always fused (HC_FUSED_PREP)
   int fused_prep = -1;
-  int fused_min_batch = 8;
+  double fused_min_batch = 16;   // thresholds below are in 720p-frame equivalents: a 360p frame counts 1/4, a 1080p frame 2.25
   int row_stages = 1;
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
 
@@ -164,7 +164,7 @@ struct hc_context {
   hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
                *d_band_items[2] = {nullptr, nullptr}, *d_seg_items[2] = {nullptr, nullptr};
   int n_seg_items[2] = {0, 0};           // bands cut into segments of seg_tiles tiles: the work list of small batches
-  int seg_tiles = 2, seg_max_batch = 2;  // HC_SEG_TILES, HC_SEG_MAX_BATCH
+  int seg_tiles = 1, seg_max_batch = 8;  // HC_SEG_TILES, HC_SEG_MAX_BATCH (measured: tools/exp_small_batch.sh)
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;
@@ -402,7 +402,9 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (c->taps_enabled) HIPCHK(hipMemsetAsync(c->d_taps, 0xFE, grid_stride * nframes, s));
     int e;
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
-    if (c->fused_prep > 0 || (c->fused_prep < 0 && nframes > c->fused_min_batch)) {
+    // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
+    const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
+    if (c->fused_prep > 0 || (c->fused_prep < 0 && equiv > c->fused_min_batch)) {
       int max_w = 0;
       for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
       // the pyramid bytes only exist as a debug tap in this mode
@@ -431,7 +433,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
     // With one or two frames neither cascade launch fills 256 CUs and a band walk is a serial chain of tiles:
     // the two launches (independent: different levels) then run side by side on two streams.
-    const bool side = nframes <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
+    const bool side = equiv <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
     if (side) {
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
@@ -439,7 +441,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
-      const bool seg = nframes <= c->seg_max_batch && c->n_seg_items[k] > 0;
+      const bool seg = equiv <= c->seg_max_batch && c->n_seg_items[k] > 0;
       A.levels = c->d_levels;
       A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
       A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
@@ -452,8 +454,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
-      e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k],
-                             c->lds_bytes[k], A);
+      e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
+                             c->band_waves[k], c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (side) {
@@ -575,6 +577,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
+  if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_TILES")) ctx->seg_tiles = std::min(255, std::max(1, atoi(e_)));

@@ -66,6 +66,7 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
                     float* vnf, size_t grid_stride);
 // rows = band height in grid rows (8, 16 or 32), nwaves = wavefronts per workgroup (4 or 8);
 // lds_bytes = tile + vnf + 2 queues + counters
-int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
+                   const CascadeArgs& args);
 
 }  // namespace hc

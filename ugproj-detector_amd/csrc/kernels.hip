@@ -577,7 +577,7 @@ __device__ __forceinline__ void fill_tile(int32_t* tile, const uint32_t* __restr
 #else
 #define PH_MARK(k) do {} while (0)
 #endif
-template <bool TREE, int ROWS, int NW>   // NW wavefronts per workgroup (4 or 8)
+template <bool TREE, int ROWS, int NW, bool SEG>   // NW wavefronts per workgroup (4 or 8); SEG: work items are band segments
 __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeArgs A) {
   constexpr int TILE_WIN = ROWS * TILE_POS;
   constexpr int NTHREADS = NW * 64;
@@ -623,9 +623,10 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
   // stage 0 on the tile to its left and applies the closed form below to position 63.  A row whose 64 positions
   // there all fail stage 0 passes its incoming bit through unchanged (64 is even), so only such rows look one
   // more tile to the left, down to the row start, whose bit is 1.
-  const int gx_begin = it.b & 0xffff;
-  const int gx_end = (it.b >> 16) ? min(nx, gx_begin + (it.b >> 16) * TILE_POS) : nx;
-  if (gx_begin > 0) {
+  // (Whole-band launches use the SEG = false instantiation: the full batches' kernel carries none of this.)
+  const int gx_begin = SEG ? (it.b & 0xffff) : 0;
+  const int gx_end = SEG && (it.b >> 16) ? min(nx, gx_begin + (it.b >> 16) * TILE_POS) : nx;
+  if (SEG && gx_begin > 0) {
     unsigned int need = 0;
     for (int j = 0; j < ROWS / NW; j++)
       if (gy0 + wave + NW * j < ny) need |= 1u << j;
@@ -929,21 +930,21 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
   return 0;
 }
 
-template <bool TREE>
+template <bool TREE, bool SEG>
 static int launch_cascade_rows(hipStream_t st, int nframes, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
   const dim3 grid(nframes, args.nbands), block(nwaves * 64);
   if (nwaves == 4) {
     switch (rows) {
-      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 4>), grid, block, lds_bytes, st, args); break;
-      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 4>), grid, block, lds_bytes, st, args); break;
-      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 4>), grid, block, lds_bytes, st, args); break;
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 4, SEG>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 4, SEG>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 4, SEG>), grid, block, lds_bytes, st, args); break;
       default: return (int)hipErrorInvalidValue;
     }
   } else if (nwaves == 8) {
     switch (rows) {
-      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 8>), grid, block, lds_bytes, st, args); break;
-      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 8>), grid, block, lds_bytes, st, args); break;
-      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 8>), grid, block, lds_bytes, st, args); break;
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 8, SEG>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 8, SEG>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 8, SEG>), grid, block, lds_bytes, st, args); break;
       default: return (int)hipErrorInvalidValue;
     }
   } else {
@@ -953,10 +954,13 @@ static int launch_cascade_rows(hipStream_t st, int nframes, int rows, int nwaves
   return 0;
 }
 
-int launch_cascade(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
+int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
+                   const CascadeArgs& args) {
   if (args.nbands == 0 || nframes == 0) return 0;
-  const int rc_ = tree ? launch_cascade_rows<true>(st, nframes, rows, nwaves, lds_bytes, args)
-              : launch_cascade_rows<false>(st, nframes, rows, nwaves, lds_bytes, args);
+  const int rc_ = tree ? (segments ? launch_cascade_rows<true, true>(st, nframes, rows, nwaves, lds_bytes, args)
+                                   : launch_cascade_rows<true, false>(st, nframes, rows, nwaves, lds_bytes, args))
+                       : (segments ? launch_cascade_rows<false, true>(st, nframes, rows, nwaves, lds_bytes, args)
+                                   : launch_cascade_rows<false, false>(st, nframes, rows, nwaves, lds_bytes, args));
 #ifdef HC_PHASE
   dump_phase(st, nwaves);
 #endif
