@@ -412,10 +412,12 @@ def test_prep_policy_by_batch_size(pkg, oracle, synth, monkeypatch):
     assert np.array_equal(one, big[5])
 
 
-def test_detect_faces_path(pkg, oracle, synth):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_detect_faces_path(pkg, oracle, synth, monkeypatch, fused):
     """SURVEY 8f-1: FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) on device --
     skin mask, equalised masked gray, the cascade call and the skin-ratio post-filter -- against the
     oracle's restatement: mask bytes, gray bytes and the surviving rectangles are bit-exact."""
+    monkeypatch.setenv("HC_FUSED_PREP", fused)   # mask integral by the fused kernel / by the row + column scans
     path = oracle.cascade_path("alt")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     frames = np.stack([synth.planted_bgr(240, 320, synth.frame_seed(i), nfaces=3, min_size=40, max_size=110)[0]

@@ -183,6 +183,8 @@ struct hc_context {
   int* d_boxes = nullptr;
   hc::DevLevel* d_idlevel = nullptr;      // identity "level" (w = cols, h = rows) for the mask integral
   uint32_t *d_idx = nullptr, *d_idy = nullptr;
+  hc::WorkItem* d_mask_items[2] = {nullptr, nullptr};   // row / column scan work lists of the mask plane (small batches)
+  int n_mask_items[2] = {0, 0};
   int* h_boxes = nullptr;                 // pinned: {frame, x, y, w, h} per grouped rect
   uint32_t* h_boxsums = nullptr;
   int box_cap = 0, mask_pitch = 0;
@@ -217,10 +219,11 @@ struct hc_context {
     h_cand = nullptr; h_count = nullptr;
     if (d_src_bgr) (void)hipFree(d_src_bgr);
     d_src_bgr = nullptr; src_rows = src_cols = 0;
-    void* fptrs[] = {d_bgr, d_gray, d_mask, d_lut, d_hist, d_msum, d_boxsums, d_boxes, d_idlevel, d_idx, d_idy};
+    void* fptrs[] = {d_bgr, d_gray, d_mask, d_lut, d_hist, d_msum, d_boxsums, d_boxes, d_idlevel, d_idx, d_idy,
+                     d_mask_items[0], d_mask_items[1]};
     for (void* q : fptrs) if (q) (void)hipFree(q);
     d_bgr = d_gray = d_mask = d_lut = nullptr; d_hist = d_msum = d_boxsums = nullptr; d_boxes = nullptr;
-    d_idlevel = nullptr; d_idx = d_idy = nullptr;
+    d_idlevel = nullptr; d_idx = d_idy = nullptr; d_mask_items[0] = d_mask_items[1] = nullptr;
     if (h_boxes) (void)hipHostFree(h_boxes);
     if (h_boxsums) (void)hipHostFree(h_boxsums);
     h_boxes = nullptr; h_boxsums = nullptr;
@@ -835,6 +838,13 @@ int hc_context_enable_faces(hc_context* ctx) {
   if ((rc = dev_upload(&ctx->d_idlevel, lv))) return rc;
   if ((rc = dev_upload(&ctx->d_idx, idx))) return rc;
   if ((rc = dev_upload(&ctx->d_idy, idy))) return rc;
+  // work lists of the parallel row / column scan kernels for the same plane (small batches)
+  std::vector<hc::WorkItem> ri, ci;
+  for (int y0 = 0; y0 < (int)rows; y0 += 4) ri.push_back(hc::WorkItem{0, y0, 0});
+  for (int x0 = 0; x0 < (int)cols; x0 += hc::WG_THREADS) ci.push_back(hc::WorkItem{0, x0, 0});
+  ctx->n_mask_items[0] = (int)ri.size(); ctx->n_mask_items[1] = (int)ci.size();
+  if ((rc = dev_upload(&ctx->d_mask_items[0], ri))) return rc;
+  if ((rc = dev_upload(&ctx->d_mask_items[1], ci))) return rc;
   HIPCHK(hipHostMalloc((void**)&ctx->h_boxes, (size_t)ctx->box_cap * 5 * sizeof(int), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_boxsums, (size_t)ctx->box_cap * sizeof(uint32_t), hipHostMallocDefault));
   ctx->faces_enabled = true;
@@ -871,9 +881,17 @@ static int faces_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_str
                                ctx->d_gray, ctx->d_mask, npix, ctx->d_hist, ctx->d_lut);
   if (e) return set_err(HC_ERR_HIP, std::string("face prep launch: ") + hipGetErrorString((hipError_t)e));
   // integral of the mask (sum only) for the skin-ratio post-filter
-  e = hc::launch_pyramid_integral(ctx->stream, nframes, 1, ctx->plan.cols, ctx->d_mask, npix, ctx->plan.cols, ctx->plan.rows,
-                                  ctx->plan.cols, ctx->d_idlevel, ctx->d_idx, ctx->d_idy, ctx->d_msum, nullptr,
-                                  ctx->mask_int_words, nullptr, 0);
+  const double equiv = (double)nframes * (double)npix / (1280.0 * 720.0);
+  if (ctx->fused_prep > 0 || (ctx->fused_prep < 0 && equiv > ctx->fused_min_batch)) {
+    e = hc::launch_pyramid_integral(ctx->stream, nframes, 1, ctx->plan.cols, ctx->d_mask, npix, ctx->plan.cols, ctx->plan.rows,
+                                    ctx->plan.cols, ctx->d_idlevel, ctx->d_idx, ctx->d_idy, ctx->d_msum, nullptr,
+                                    ctx->mask_int_words, nullptr, 0);
+  } else {   // small batch: row scans, then column scans, each fully parallel (same policy as the pyramid prep)
+    e = hc::launch_integral_rows(ctx->stream, nframes, ctx->n_mask_items[0], ctx->d_mask, npix, ctx->d_idlevel,
+                                 ctx->d_mask_items[0], ctx->d_msum, nullptr, ctx->mask_int_words);
+    if (!e) e = hc::launch_integral_cols(ctx->stream, nframes, ctx->n_mask_items[1], ctx->d_idlevel, ctx->d_mask_items[1],
+                                         ctx->d_msum, nullptr, ctx->mask_int_words);
+  }
   if (e) return set_err(HC_ERR_HIP, std::string("mask integral launch: ") + hipGetErrorString((hipError_t)e));
   int rc = enqueue_device(ctx, ctx->d_gray, npix, ctx->plan.cols, nframes);
   if (rc == HC_OK) ctx->faces_pending = true;

@@ -93,14 +93,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_rows(
   const uint8_t* src = pyr + (size_t)blockIdx.y * pyr_stride + L.pyr_ofs + (size_t)row * w;
   const size_t o = (size_t)blockIdx.y * int_stride + L.int_ofs + (size_t)(row + 1) * L.int_pitch + 1;
   uint32_t* S = sum + o;
-  uint32_t* Q = sq + o;
+  uint32_t* Q = sq ? sq + o : nullptr;          // sq == nullptr: sum only (mask integral of the detectFaces path)
   uint32_t carry_s = 0, carry_q = 0;
   for (int x0 = 0; x0 < w; x0 += 64) {
     const int x = x0 + lane;
     const uint32_t p = x < w ? src[x] : 0u;
     const uint32_t s = wave_scan_u32(p) + carry_s;
     const uint32_t q = wave_scan_u32(p * p) + carry_q;
-    if (x < w) { S[x] = s; Q[x] = q; }
+    if (x < w) { S[x] = s; if (Q) Q[x] = q; }
     carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
     carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
   }
@@ -119,6 +119,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_cols(
   const int pitch = L.int_pitch, h = L.h;
   const size_t o = (size_t)blockIdx.y * int_stride + L.int_ofs + (size_t)pitch + x + 1;
   uint32_t* S = sum + o;
+  if (!sq) {                                    // sum only
+    uint32_t as = 0;
+    for (int y = 0; y < h; y++) { as += S[(size_t)y * pitch]; S[(size_t)y * pitch] = as; }
+    return;
+  }
   uint32_t* Q = sq + o;
   uint32_t as = 0, aq = 0;
   int y = 0;
