@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     const int sizes[][2] = {{720, 1280}, {360, 640}, {1080, 1920}, {97, 131}, {20, 20}, {19, 300}, {2160, 3840}};
     for (const auto& s : sizes) {
       hc::Plan p;
-      if (hc::build_plan(m, s[0], s[1], 1.1, 30, 30, 0, 0, 16, 8, p) != 0) return 2;
+      if (hc::build_plan(m, s[0], s[1], 1.1, 30, 30, 0, 0, 16, 16, p) != 0) return 2;
       size_t words = 0;
       for (const auto& L : p.levels) words += (size_t)L.int_pitch * (L.h + 1) + 32;
       if ((int64_t)words != p.int_words) return 3;

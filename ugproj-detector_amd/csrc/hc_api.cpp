@@ -1014,7 +1014,7 @@ int hc_plan_query(const hc_cascade* c, int rows, int cols, double scale_factor, 
                   int max_h, hc_level* levels, int cap, int* nlevels, int64_t* algorithmic_bytes) {
   if (!c || !nlevels) return set_err(HC_ERR_ARG, "null argument");
   hc::Plan P;
-  int rc = hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, 16, 8, P);
+  int rc = hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, 16, 16, P);
   if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
   *nlevels = (int)P.levels.size();
   if (algorithmic_bytes) *algorithmic_bytes = P.algorithmic_bytes;

@@ -24,7 +24,7 @@ struct Plan {
   std::vector<WorkItem> col_items;    // 256 columns per block
   std::vector<WorkItem> var_items;    // 256 grid positions of one grid row segment per block
   std::vector<WorkItem> band_items[2];  // cascade kernel: bands of band_rows[c] grid rows; c = 0: ystep 1, 1: ystep 2
-  int band_rows[2] = {16, 8};
+  int band_rows[2] = {16, 16};
 
   int64_t pyr_bytes = 0;    // per frame
   int64_t int_words = 0;    // per frame, per integral array
