@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step (one launch of every kernel)")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic frames per rank (cycled)")
     ap.add_argument("--kind", default="planted", choices=["planted", "texture", "noise"])
     ap.add_argument("--cascade", default="alt")
@@ -209,10 +209,10 @@ def main():
             traffic, traffic_src = None, None
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if tf and B == 64 and args.kind == "planted" and args.cascade == "alt":
+            if tf and args.kind == "planted" and args.cascade == "alt":    # measured at the default workload; scaled per frame
                 try:
                     tj = json.load(open(tf[-1]))
-                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                    traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"] * B / tj.get("frames_per_launch", 64))
                     traffic_src = os.path.relpath(tf[-1], ROOT)
                 except Exception:
                     traffic = None

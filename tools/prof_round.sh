@@ -16,5 +16,6 @@ rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pm
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq1 -- python3 $ARGS > $O/pmc_sq1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq2 -- python3 $ARGS > $O/pmc_sq2.log 2>&1 || exit 1
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.txt
-python3 $R/tools/traffic_from_pmc.py $O $O/traffic.json > /dev/null
+FRAMES=$(python3 -c "import json; print(json.loads(open('$O/bench.json').read().strip().splitlines()[-1])['config']['frames_per_gpu_per_step'])")
+python3 $R/tools/traffic_from_pmc.py $O $O/traffic.json $FRAMES > /dev/null
 cat $O/bench.json; head -8 $O/kernel_stats.csv | cut -c1-160

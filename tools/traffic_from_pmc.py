@@ -3,7 +3,8 @@
 MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of a streaming read (TCC_EA0_RDREQ tallied at 64 B for
 128-B requests) -> doubled; WRITE_SIZE is exact.  Writes profiles/<tag>_traffic.json, which bench.py
-reports as roofline.traffic (per 64-frame launch; the two k_cascade launches of a batch are summed)."""
+reports as roofline.traffic (per launch of frames_per_launch frames, scaled to its own batch size; the two
+k_cascade launches of a batch are summed).  usage: traffic_from_pmc.py <pmc dir> <out.json> [frames per launch]"""
 import collections
 import csv
 import glob
@@ -11,6 +12,7 @@ import json
 import sys
 
 root, out = sys.argv[1], sys.argv[2]
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -25,6 +27,7 @@ for k, d in acc.items():
     write = sum(sum(v) / len(v) for n, v in d.items() if n.startswith("WRITE_SIZE"))
     res[k] = {"fetch_bytes_corrected": int(fetch * 1024 * 2), "write_bytes": int(write * 1024),
               "hbm_bytes_per_launch": int(fetch * 1024 * 2 + write * 1024)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 4, 64 frames per launch",
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 4, %d frames per launch" % frames,
+           "frames_per_launch": frames,
            "correction": "FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1", "kernels": res}, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
