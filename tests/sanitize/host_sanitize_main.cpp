@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -55,6 +56,46 @@ int main(int argc, char** argv) {
     const int lo[3] = {0, 133, 77}, hi[3] = {255, 173, 127};
     if (orc_detect_faces(oc, bgr.data(), 120, 160, 480, lo, hi, 1.1, out.data(), 1024, &n, nullptr, nullptr)) return 6;
     orc_cascade_free(oc);
+  }
+  // malformed HCC1 containers must be rejected by the loader (never indexed out of bounds later):
+  // truncations at every 997th byte, a stage with zero / negative / oversized tree counts, a window <= 2
+  {
+    std::string good;
+    if (FILE* f = fopen(argv[1], "rb")) {
+      char tmp[1 << 16];
+      size_t n;
+      while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) good.append(tmp, n);
+      fclose(f);
+    }
+    if (good.size() > 64 && good.compare(0, 4, "HCC1") == 0) {
+      const std::string ppath = std::string(argv[0]) + ".poison.hcc";
+      auto try_load = [&](const std::string& bytes) {
+        FILE* f = fopen(ppath.c_str(), "wb");
+        if (!f) return -100;
+        fwrite(bytes.data(), 1, bytes.size(), f);
+        fclose(f);
+        hc::Model m;
+        std::string err;
+        return hc::load_model(ppath, m, err);
+      };
+      if (try_load(good) != 0) return 7;
+      for (size_t cut = 0; cut < good.size(); cut += 997)
+        if (try_load(good.substr(0, cut)) == 0) return 8;
+      auto poke = [&](size_t ofs, int32_t v) { std::string b = good; memcpy(&b[ofs], &v, 4); return b; };
+      // header: magic, win_w, win_h, nstages, ntrees, nnodes, nleaves, flags; stage record: f64 thr, i32 ntrees, parent, next
+      const size_t stage0_ntrees = 4 + 28 + 8, stage1_ntrees = stage0_ntrees + 20;
+      int32_t n0, n1;
+      memcpy(&n0, &good[stage0_ntrees], 4);
+      memcpy(&n1, &good[stage1_ntrees], 4);
+      if (try_load(poke(stage0_ntrees, 0)) == 0) return 9;                       // counts no longer add up
+      { std::string b = poke(stage0_ntrees, 0); int32_t v = n0 + n1; memcpy(&b[stage1_ntrees], &v, 4);
+        if (try_load(b) == 0) return 10; }                                        // sums match, stage 0 is empty
+      { std::string b = poke(stage0_ntrees, -3); int32_t v = n0 + n1 + 3; memcpy(&b[stage1_ntrees], &v, 4);
+        if (try_load(b) == 0) return 11; }                                        // negative tree count
+      if (try_load(poke(4, 2)) == 0) return 12;                                  // win_w = 2: normrect would be empty
+      if (try_load(poke(8, 200)) == 0) return 13;                                // window taller than the 8-bit rect fields
+      remove(ppath.c_str());
+    }
   }
   for (int it = 0; it < 200; it++) {
     std::vector<hc_rect> r;

@@ -202,6 +202,31 @@ int validate(Model& m, std::string& err) {
   static const float kThresholdEps = 1e-5f;
   for (auto& s : m.stages) s.thr = (float)s.thr_raw - kThresholdEps;
   if (m.has_tilted) { err = "tilted Haar features are not supported"; return HC_ERR_UNSUPPORTED; }
+  // both parsers end here: everything the host planner and the kernels index without further checks
+  if (m.win_w <= 2 || m.win_h <= 2 || m.win_w > 127 || m.win_h > 127) { err = "window size out of range"; return HC_ERR_FORMAT; }
+  if (m.stages.empty() || m.trees.empty()) { err = "empty cascade"; return HC_ERR_FORMAT; }
+  {
+    size_t next_tree = 0;
+    for (const auto& s : m.stages) {
+      if (s.ntrees < 1 || s.first_tree < 0 || (size_t)s.first_tree != next_tree ||
+          (size_t)s.first_tree + (size_t)s.ntrees > m.trees.size()) {
+        err = "stage with no trees / tree range outside the model";
+        return HC_ERR_FORMAT;
+      }
+      next_tree += (size_t)s.ntrees;
+    }
+    if (next_tree != m.trees.size()) { err = "trees not covered by the stages"; return HC_ERR_FORMAT; }
+    size_t next_node = 0, next_leaf = 0;
+    for (const auto& t : m.trees) {
+      if (t.nnodes < 1 || (size_t)t.first_node != next_node || (size_t)t.first_leaf != next_leaf) {
+        err = "tree node / leaf ranges inconsistent";
+        return HC_ERR_FORMAT;
+      }
+      next_node += (size_t)t.nnodes;
+      next_leaf += (size_t)t.nnodes + 1;
+    }
+    if (next_node != m.nodes.size() || next_leaf != m.leaves.size()) { err = "node / leaf counts inconsistent"; return HC_ERR_FORMAT; }
+  }
   for (const auto& t : m.trees) {
     for (int k = 0; k < t.nnodes; k++) {
       ModelNode& n = m.nodes[t.first_node + k];
