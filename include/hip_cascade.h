@@ -40,7 +40,7 @@ typedef enum hc_status {
   HC_ERR_NO_DEVICE = -5,     /* no HIP device / HIP runtime error at init          */
   HC_ERR_HIP = -6,           /* HIP runtime error (hc_last_error() has the text)   */
   HC_ERR_CAPACITY = -7,      /* caller's output buffer too small                   */
-  HC_ERR_CAND_OVERFLOW = -8, /* raw-candidate workspace overflow (raise cand_capacity) */
+  HC_ERR_CAND_OVERFLOW = -8, /* raw-candidate workspace overflow that could not be grown (normally it grows and the batch re-runs) */
   HC_ERR_STATE = -9          /* call order violated (e.g. wait without enqueue)    */
 } hc_status;
 
@@ -76,6 +76,19 @@ HC_API int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, in
                                 double scale_factor, int min_neighbors, int flags,
                                 int min_w, int min_h, int max_w, int max_h,
                                 hc_rect* out, int out_capacity, int* out_count);
+
+/* The same call on an image with `channels` interleaved 8-bit channels: 1 (gray), or 3 / 4 (BGR / BGRA), which
+ * upstream's detectMultiScale first converts with cvtColor(image, gray, COLOR_BGR2GRAY) (SURVEY 8b "Semantics").
+ * The reference passes one channel (src/tracker/detector.cc:20-22); a caller that hands the colour frame
+ * straight to the classifier gets upstream's behaviour instead of an error. */
+HC_API int hc_detect_multiscale_image(hc_cascade* c, const uint8_t* image, int rows, int cols, int channels,
+                                      size_t step_bytes, double scale_factor, int min_neighbors, int flags,
+                                      int min_w, int min_h, int max_w, int max_h,
+                                      hc_rect* out, int out_capacity, int* out_count);
+/* cvtColor(image, gray, COLOR_BGR2GRAY) alone (reference src/tracker/detector.cc:20), host in / host out, on the
+ * current device: (3735 B + 19235 G + 9798 R + 16384) >> 15.  channels = 3 or 4. */
+HC_API int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int channels, size_t step_bytes,
+                               uint8_t* gray, size_t gray_step_bytes);
 
 /* ---- page-locked host memory for the frame pool of the throughput path ------------------ */
 HC_API int  hc_host_alloc(size_t bytes, void** out);       /* hipHostMalloc; free with hc_host_free */
@@ -125,14 +138,30 @@ HC_API int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols
 HC_API int hc_context_enable_faces(hc_context* ctx);
 /* Scan-size resize ahead of detectFaces: cv::resize(orig, curr, cfg.scan.frame_size, 0, 0, INTER_AREA)
  * (reference src/tracker/face_tracker.cc:112-114).  After this call the faces enqueue functions take
- * src_rows x src_cols BGR frames and decimate them on device to the configured rows x cols.  Integer
- * decimation factors only (1280x720 -> 640x360 under the shipped cfg); otherwise HC_ERR_UNSUPPORTED. */
+ * src_rows x src_cols BGR frames and shrink them on device to the configured rows x cols: the box average
+ * for integer ratios (1280x720 -> 640x360 under the shipped cfg), upstream's weighted cell coverage for any
+ * other ratio.  A scan size larger than the source in either axis is HC_ERR_UNSUPPORTED. */
 HC_API int hc_context_enable_scan_resize(hc_context* ctx, int src_rows, int src_cols);
 HC_API int hc_faces_batch_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_stride_bytes,
                                   size_t row_step_bytes, int nframes, const int lower[3], const int upper[3]);
 HC_API int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t frame_stride_bytes,
                                        size_t row_step_bytes, int nframes, const int lower[3], const int upper[3]);
 HC_API int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets);
+
+/* ---- box files: frame id -> rect list, the hand-over from a batched / multi-GPU detection run
+ * to the sequential tracker, which consumes every box of every frame in frame order (reference
+ * src/tracker/face_tracker.cc:123-148, :294-302; the reference only has a TODO for tracker metadata files,
+ * src/file_io.h:41-48).  Little endian: "HCBX", int32 version = 1, int32 nframes, then per frame in ascending
+ * frame id: int32 frame_id, int32 count, count x {int32 x, y, width, height}.  Same bytes as
+ * ugproj-detector_amd/shard.py save_boxes / load_boxes.  Pure host code, needs no device.
+ * save: frame i has id frame_ids[i] and rects[offsets[i] .. offsets[i+1]) (the layout hc_detect_batch_wait returns);
+ *       frames may come in any order, ids must be distinct.
+ * load: *nframes / *nrects always receive the file's sizes; with null output pointers it is a size query;
+ *       HC_ERR_CAPACITY when the buffers are too small. */
+HC_API int hc_boxes_save(const char* path, int nframes, const int32_t* frame_ids, const int32_t* offsets,
+                         const hc_rect* rects);
+HC_API int hc_boxes_load(const char* path, int32_t* frame_ids, int32_t* offsets, int frame_capacity,
+                         hc_rect* rects, int rect_capacity, int* nframes, int* nrects);
 
 /* ---- plan introspection (tests, bench accounting) -------------------------------------- */
 typedef struct hc_level {

@@ -682,6 +682,22 @@ int orc_detect_many(const orc_cascade* c, const uint8_t* frames, int nframes, in
   return err;
 }
 
+// cvtColor(src, gray, COLOR_BGR2GRAY) for 8UC3 / 8UC4 (revised in round 2): OpenCV >= 4 computes the
+// 8-bit gray with the 15-bit coefficient set RY15/GY15/BY15 and gray_shift = 15, while the Y of BGR2YCrCb keeps the
+// 14-bit R2Y/G2Y/B2Y with yuv_shift = 14 (orc_detect_faces below).  The two differ by +-1 on some pixels.
+// [UPSTREAM-RECALL, parity unpinned: no OpenCV here and no fixture in the reference]
+static inline int gray15(int b, int g, int r) { return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15; }
+
+int orc_bgr2gray(const uint8_t* src, int rows, int cols, int channels, size_t step, uint8_t* gray) {
+  if (rows <= 0 || cols <= 0 || (channels != 3 && channels != 4)) return -2;
+  for (int y = 0; y < rows; y++) {
+    const uint8_t* p = src + (size_t)y * step;
+    for (int x = 0; x < cols; x++)
+      gray[(size_t)y * cols + x] = (uint8_t)gray15(p[(size_t)channels * x], p[(size_t)channels * x + 1], p[(size_t)channels * x + 2]);
+  }
+  return 0;
+}
+
 // FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43), OpenCV 8-bit paths per SURVEY A.13
 int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step, const int lower[3],
                      const int upper[3], double scale_factor, orc_rect* out, int cap, int* out_count,
@@ -695,13 +711,14 @@ int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int col
     const uint8_t* p = bgr + (size_t)y * step;
     for (int x = 0; x < cols; x++) {
       const int b = p[3 * x], g = p[3 * x + 1], r = p[3 * x + 2];
-      const int Y = (b * B2Y + g * G2Y + r * R2Y + half) >> shift;       // cvtColor(BGR2YCrCb).Y == cvtColor(BGR2GRAY)
+      const int Y = (b * B2Y + g * G2Y + r * R2Y + half) >> shift;       // cvtColor(BGR2YCrCb).Y: yuv_shift = 14
       const int Cr = sat8(((r - Y) * YCRI + delta + half) >> shift);
       const int Cb = sat8(((b - Y) * YCBI + delta + half) >> shift);
       const bool in = Y >= lower[0] && Y <= upper[0] && Cr >= lower[1] && Cr <= upper[1] && Cb >= lower[2] && Cb <= upper[2];
       mask[(size_t)y * cols + x] = in ? 255 : 0;                          // inRange
-      gray[(size_t)y * cols + x] = (uint8_t)Y;
-      hist[Y]++;
+      const int G = gray15(b, g, r);                                      // cvtColor(BGR2GRAY): gray_shift = 15
+      gray[(size_t)y * cols + x] = (uint8_t)G;
+      hist[G]++;
     }
   }
   // equalizeHist
@@ -742,18 +759,69 @@ int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int col
   return 0;
 }
 
+// cv::resize(..., INTER_AREA), 8-bit, 1 or 3 interleaved channels, both axes shrinking (scale >= 1).
+// Integer factors: resizeAreaFast_ (2x2: (a+b+c+d+2)>>2; else cvRound(sum * (1.f/area))).  Any other ratio:
+// computeResizeAreaTab + resizeArea_<uchar, float>: per destination pixel the source cells it covers, weighted
+// by the covered fraction (f64 table arithmetic rounded to f32), accumulated in f32 in table order -- per source
+// row buf = sum_k S[sx_k] * alpha_k, then sum = beta_0 * buf_0 + beta_1 * buf_1 + ..., then
+// saturate_cast<uchar>(sum) = cvRound.  One f32 rounding per written operation, no FMA.  [UPSTREAM-RECALL, unpinned]
+namespace {
+struct AreaTap { int si; float alpha; };
+// taps of every destination index: ofs[d] .. ofs[d+1]
+void area_table(int ssize, int dsize, double scale, std::vector<AreaTap>& tab, std::vector<int>& ofs) {
+  tab.clear();
+  ofs.assign(dsize + 1, 0);
+  for (int dx = 0; dx < dsize; dx++) {
+    ofs[dx] = (int)tab.size();
+    const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    const double cell = std::min(scale, ssize - fsx1);
+    int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+    sx2 = std::min(sx2, ssize - 1);
+    sx1 = std::min(sx1, sx2);
+    if (sx1 - fsx1 > 1e-3) tab.push_back(AreaTap{sx1 - 1, (float)((sx1 - fsx1) / cell)});
+    for (int sx = sx1; sx < sx2; sx++) tab.push_back(AreaTap{sx, (float)(1.0 / cell)});
+    if (fsx2 - sx2 > 1e-3) tab.push_back(AreaTap{sx2, (float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)});
+  }
+  ofs[dsize] = (int)tab.size();
+}
+}  // namespace
+
 int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t step, uint8_t* dst, int drows, int dcols) {
-  if (drows <= 0 || dcols <= 0 || rows % drows || cols % dcols || (channels != 1 && channels != 3)) return -4;
-  const int fy = rows / drows, fx = cols / dcols;
-  const float scale = 1.f / (float)(fx * fy);
+  if (drows <= 0 || dcols <= 0 || drows > rows || dcols > cols || (channels != 1 && channels != 3)) return -4;
+  if (rows % drows == 0 && cols % dcols == 0) {
+    const int fy = rows / drows, fx = cols / dcols;
+    const float scale = 1.f / (float)(fx * fy);
+    for (int y = 0; y < drows; y++)
+      for (int x = 0; x < dcols; x++)
+        for (int ch = 0; ch < channels; ch++) {
+          int sum = 0;
+          for (int j = 0; j < fy; j++)
+            for (int i = 0; i < fx; i++) sum += src[(size_t)(y * fy + j) * step + (size_t)(x * fx + i) * channels + ch];
+          int v = (fx == 2 && fy == 2) ? (sum + 2) >> 2 : cv_round((float)sum * scale);
+          dst[((size_t)y * dcols + x) * channels + ch] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    return 0;
+  }
+  std::vector<AreaTap> xt, yt;
+  std::vector<int> xo, yo;
+  area_table(cols, dcols, (double)cols / dcols, xt, xo);
+  area_table(rows, drows, (double)rows / drows, yt, yo);
   for (int y = 0; y < drows; y++)
     for (int x = 0; x < dcols; x++)
       for (int ch = 0; ch < channels; ch++) {
-        int sum = 0;
-        for (int j = 0; j < fy; j++)
-          for (int i = 0; i < fx; i++) sum += src[(size_t)(y * fy + j) * step + (size_t)(x * fx + i) * channels + ch];
-        int v = (fx == 2 && fy == 2) ? (sum + 2) >> 2 : cv_round((float)sum * scale);
-        dst[((size_t)y * dcols + x) * channels + ch] = (uint8_t)(v > 255 ? 255 : v);
+        float sum = 0.f;
+        for (int j = yo[y]; j < yo[y + 1]; j++) {
+          const uint8_t* S = src + (size_t)yt[j].si * step;
+          float buf = 0.f;
+          for (int k = xo[x]; k < xo[x + 1]; k++) {
+            const float t = (float)S[(size_t)xt[k].si * channels + ch] * xt[k].alpha;
+            buf = buf + t;
+          }
+          const float t = yt[j].alpha * buf;
+          sum = (j == yo[y]) ? t : sum + t;
+        }
+        const int v = cv_round(sum);
+        dst[((size_t)y * dcols + x) * channels + ch] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
       }
   return 0;
 }

@@ -106,13 +106,18 @@ int orc_detect_faces(const orc_cascade* c, const uint8_t* bgr, int rows, int col
                      const int lower[3], const int upper[3], double scale_factor,
                      orc_rect* out, int cap, int* out_count, uint8_t* mask_tap, uint8_t* gray_tap);
 
-/* cv::resize(src, dst, dsize, 0, 0, INTER_AREA) for 8-bit images with 1 or 3 interleaved channels and
- * an INTEGER decimation factor in each direction -- the scan-size resize of the tracker (reference
- * src/tracker/face_tracker.cc:112-114; 1280x720 -> 640x360 under conf/apink.mrchu.720p.cfg:4).
- * Factor 2x2: (a+b+c+d+2)>>2 (ResizeAreaFastVec); other integer factors: cvRound(sum * (1.f/area))
- * (resizeAreaFast_).  Non-integer ratios are not restated (returns -4).  [UPSTREAM-RECALL, unpinned] */
+/* cv::resize(src, dst, dsize, 0, 0, INTER_AREA) for 8-bit images with 1 or 3 interleaved channels, both
+ * axes shrinking -- the scan-size resize of the tracker (reference src/tracker/face_tracker.cc:112-114;
+ * 1280x720 -> 640x360 under conf/apink.mrchu.720p.cfg:4, but scan.frame_size accepts any size).
+ * Integer factors: 2x2 (a+b+c+d+2)>>2 (ResizeAreaFastVec), otherwise cvRound(sum * (1.f/area))
+ * (resizeAreaFast_).  Other ratios: computeResizeAreaTab + resizeArea_<uchar,float> (f32 accumulation in
+ * table order, cvRound at the end).  Enlarging in either axis returns -4.  [UPSTREAM-RECALL, unpinned] */
 int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t step,
                     uint8_t* dst, int drows, int dcols);
+
+/* cvtColor(src, gray, COLOR_BGR2GRAY) for 8UC3 / 8UC4: (3735 B + 19235 G + 9798 R + 16384) >> 15 -- what
+ * detectMultiScale applies to a multi-channel image and FaceDetector::detectFaces at detector.cc:20. */
+int orc_bgr2gray(const uint8_t* src, int rows, int cols, int channels, size_t step, uint8_t* gray);
 
 /* Evaluate one window-sized patch (win_h x win_w, tight) at scale 1: returns number of
  * stages passed (nstages = accepted), -1 if not evaluable. margins (optional, nstages

@@ -342,3 +342,75 @@ def detect(c, gray, sf=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), w
     if want_taps:
         return grouped, raw, taps_all
     return grouped, raw
+
+
+# ----------------------------------------------------------------------------- adjacent ops
+def bgr2gray(img):
+    """cvtColor(BGR2GRAY), 8-bit: the 15-bit coefficient set (gray_shift = 15)."""
+    a = np.asarray(img).astype(np.int64)
+    return ((a[..., 0] * 3735 + a[..., 1] * 19235 + a[..., 2] * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def bgr2ycrcb_y(img):
+    """Y channel of cvtColor(BGR2YCrCb), 8-bit: the 14-bit coefficient set (yuv_shift = 14)."""
+    a = np.asarray(img).astype(np.int64)
+    return (a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14
+
+
+def _area_weights(ssize, dsize):
+    """Dense [dsize, ssize] f32 weight matrix + per-row tap order of INTER_AREA's general path.  Written from the
+    cell-coverage definition (how much of source cell s lies inside destination cell d, over the cell width) with the
+    1e-3 edge rule of computeResizeAreaTab, not from the tap loop of the C++ oracle."""
+    scale = F64(ssize) / F64(dsize)
+    W = np.zeros((dsize, ssize), F32)
+    order = []
+    for d in range(dsize):
+        lo, hi = F64(d) * scale, F64(d) * scale + scale
+        cell = min(scale, F64(ssize) - lo)
+        first_full, end_full = math.ceil(lo), min(math.floor(hi), ssize - 1)
+        first_full = min(first_full, end_full)
+        taps = []
+        if first_full - lo > 1e-3:
+            W[d, first_full - 1] = F32((first_full - lo) / cell)
+            taps.append(first_full - 1)
+        for s in range(first_full, end_full):
+            W[d, s] = F32(1.0 / cell)
+            taps.append(s)
+        if hi - end_full > 1e-3:
+            W[d, end_full] = F32(min(min(hi - end_full, 1.0), cell) / cell)
+            taps.append(end_full)
+        order.append(taps)
+    return W, order
+
+
+def resize_area(img, drows, dcols):
+    """cv::resize(INTER_AREA) for shrinking 8-bit images (HxW or HxWxC), integer and non-integer ratios."""
+    a = np.asarray(img)
+    rows, cols = a.shape[:2]
+    if a.ndim == 2:
+        a = a[:, :, None]
+    ch = a.shape[2]
+    if rows % drows == 0 and cols % dcols == 0:
+        fy, fx = rows // drows, cols // dcols
+        blk = a.astype(np.int64).reshape(drows, fy, dcols, fx, ch).sum(axis=(1, 3))
+        out = (blk + 2) >> 2 if (fx, fy) == (2, 2) else np.rint(blk.astype(F32) * (F32(1) / F32(fx * fy))).astype(np.int64)
+    else:
+        Wx, ox = _area_weights(cols, dcols)
+        Wy, oy = _area_weights(rows, drows)
+        out = np.zeros((drows, dcols, ch), np.int64)
+        src = a.astype(F32)
+        # horizontal pass: buf[sy, dx, c] accumulated tap by tap in f32 (left to right)
+        buf = np.zeros((rows, dcols, ch), F32)
+        for dx in range(dcols):
+            acc = np.zeros((rows, ch), F32)
+            for sx in ox[dx]:
+                acc = (acc + src[:, sx, :] * Wx[dx, sx]).astype(F32)
+            buf[:, dx, :] = acc
+        for dy in range(drows):
+            acc = None
+            for sy in oy[dy]:
+                t = (Wy[dy, sy] * buf[sy]).astype(F32)
+                acc = t if acc is None else (acc + t).astype(F32)
+            out[dy] = np.rint(acc).astype(np.int64)
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if np.asarray(img).ndim == 2 else out

@@ -59,6 +59,7 @@ def lib():
         L.orc_detect_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_int] * 6 + \
                                      [C.c_void_p]
         L.orc_eval_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_bgr2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.orc_resize_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.orc_detect_faces.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
@@ -174,8 +175,18 @@ def resize_linear_exact(img, drows, dcols):
     return dst
 
 
+def bgr2gray(img):
+    """cvtColor(BGR2GRAY) of an HxWx3 / HxWx4 uint8 image"""
+    img = np.ascontiguousarray(img, np.uint8)
+    g = np.zeros(img.shape[:2], np.uint8)
+    rc = lib().orc_bgr2gray(img.ctypes.data, img.shape[0], img.shape[1], img.shape[2], img.strides[0], g.ctypes.data)
+    if rc:
+        raise RuntimeError("orc_bgr2gray %d" % rc)
+    return g
+
+
 def resize_area(img, drows, dcols):
-    """cv::resize(..., INTER_AREA) for integer decimation factors; img HxW or HxWx3 uint8"""
+    """cv::resize(..., INTER_AREA), shrinking in both axes; img HxW or HxWx3 uint8"""
     img = np.ascontiguousarray(img, np.uint8)
     ch = 1 if img.ndim == 2 else img.shape[2]
     dst = np.zeros((drows, dcols) if ch == 1 else (drows, dcols, ch), np.uint8)

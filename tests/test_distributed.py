@@ -37,36 +37,55 @@ def test_pack_unpack_roundtrip(pkg):
     import importlib
     shard = importlib.import_module("ugproj_detector_amd.shard")
     boxes = [np.array([[1, 2, 3, 4], [5, 6, 7, 8]], np.int32), np.zeros((0, 4), np.int32),
-             np.arange(4 * 70, dtype=np.int32).reshape(70, 4)]
-    rec = shard.pack_records([10, 11, 12], boxes)
-    assert rec.shape == (3, shard.RECORD_INTS)
-    out = shard.unpack_records(rec)
+             np.arange(4 * 70, dtype=np.int32).reshape(70, 4), np.arange(4 * 64, dtype=np.int32).reshape(64, 4)]
+    rec = shard.pack_records([10, 11, 12, 13], boxes)
+    assert rec.shape == (4, shard.RECORD_INTS)
+    out = shard.unpack_records(rec)                                  # fixed part only
     assert out[10][0] == 2 and out[10][1].tolist() == boxes[0].tolist()
     assert out[11][0] == 0 and len(out[11][1]) == 0
-    assert out[12][0] == 70 and out[12][1].tolist() == boxes[2][:shard.MAX_BOXES].tolist()   # overflow flagged by count
+    assert out[12][0] == 70 and out[12][1].tolist() == boxes[2][:shard.MAX_BOXES].tolist()   # count > K flags the overflow
+    assert out[13][0] == 64 and out[13][1].tolist() == boxes[3].tolist()                     # exactly K: no overflow
+    ov = shard.pack_overflow(boxes)
+    assert ov.tolist() == boxes[2][shard.MAX_BOXES:].tolist()
+    assert shard.overflow_counts(rec, 1).tolist() == [6] and shard.overflow_counts(rec, 2).tolist() == [0, 6]
+    full = shard.unpack_records(rec, [ov])                           # fixed part + overflow block = every box
+    for fid, b in zip([10, 11, 12, 13], boxes):
+        assert full[fid][0] == len(b) and full[fid][1].tolist() == b.tolist()
+    with pytest.raises(ValueError):
+        shard.unpack_records(rec, [ov[:-1]])                         # a short block is an error, never a silent loss
+    # without a process group the gather is the identity and still lossless
+    got = shard.gather_boxes([10, 11, 12, 13], boxes)
+    for fid, b in zip([10, 11, 12, 13], boxes):
+        assert got[fid].tolist() == b.tolist()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_gather_of_box_records(pkg, tmp_path, world):
+@pytest.mark.parametrize("world,overflow", [(2, True), (3, True), (2, False)])
+def test_gloo_gather_of_box_records(pkg, tmp_path, world, overflow):
+    """Every box of every frame of every rank arrives at rank 0, addressable by global frame id -- including
+    frames with more than MAX_BOXES boxes (second, variable-length all-gather; ranks overflow by different
+    amounts and rank padding records carry none)."""
     import importlib
+    import json
     shard = importlib.import_module("ugproj_detector_amd.shard")
     sys.path.insert(0, HERE)
     import _dist_worker
     nglobal = 37
-    out = str(tmp_path / "gathered.npy")
+    out = str(tmp_path / "gathered.hcbx")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(nglobal), out],
-                              env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dist_worker.py"), str(r), str(world), str(nglobal), out,
+                               "overflow" if overflow else "nooverflow"], env=env) for r in range(world)]
     for p in procs:
         assert p.wait(timeout=240) == 0
-    got = shard.unpack_records(np.load(out))
-    got.pop(-1, None)                                   # padding records
+    got = shard.load_boxes(out)
+    res = dict(json.load(open(out + ".json")), records=np.load(out + ".rec.npy"))
     assert sorted(got) == list(range(nglobal))          # every frame exactly once, addressable by id
+    nover = 0
     for fid in range(nglobal):
-        want = _dist_worker.fake_boxes(fid)
-        cnt, boxes = got[fid]
-        assert cnt == len(want)
-        assert boxes.tolist() == want[:shard.MAX_BOXES].tolist()
+        want = _dist_worker.fake_boxes(fid, overflow)
+        assert got[fid].tolist() == want.tolist(), fid  # the FULL list, in order
+        nover += max(0, len(want) - shard.MAX_BOXES)
+    assert res["overflow_boxes"] == nover and (nover > 0) == overflow
+    assert res["records"].shape == (world * ((nglobal + world - 1) // world), shard.RECORD_INTS)
 
 
 def test_box_file_roundtrip(pkg, tmp_path):
@@ -84,3 +103,19 @@ def test_box_file_roundtrip(pkg, tmp_path):
     (tmp_path / "bad").write_bytes(b"nope")
     with pytest.raises(ValueError):
         shard.load_boxes(str(tmp_path / "bad"))
+
+
+def test_bench_spawns_its_own_ranks_and_reports_failures(pkg):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver invokes it): the parent starts
+    the rank processes itself before touching any GPU API.  This container has no GPU, so every rank stops with
+    "needs an MI355X" -- the parent must relay that as a non-zero exit instead of hanging or printing a number."""
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the spawn path is covered by tests/test_gpu_bench_route.py")
+    assert r.returncode != 0
+    assert "rank" in r.stderr and "MI355X" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

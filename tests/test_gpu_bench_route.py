@@ -1,0 +1,181 @@
+"""GPU parity on the route bench.py times, at BASELINE.json's full sizes, and through the shard / gather path.
+
+No environment knobs anywhere in this module: whatever the library's own policy picks for these batch sizes
+is what is compared with the oracle -- for B >= 17 frames of 1280x720 that is the fused k_pyramid_integral and
+the whole-band `k_cascade<.., SEG = false>` instantiations, i.e. exactly the kernels of BENCH_rNN.json.
+"""
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CALL = dict(scale_factor=1.1, min_neighbors=2, min_size=(30, 30))      # reference detector.cc:25-31
+
+
+@pytest.fixture(autouse=True)
+def _no_knobs(monkeypatch):
+    for k in list(os.environ):
+        if k.startswith("HC_"):
+            monkeypatch.delenv(k)
+
+
+def _oracle_many(oc, frames, want_taps):
+    """oracle results of every frame, frame-parallel (ctypes releases the GIL)"""
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        return list(ex.map(lambda f: oc.detect(f, 1.1, 2, (30, 30), (0, 0), want_taps=want_taps), frames))
+
+
+def test_bench_route_taps_720p_batch24(pkg, oracle, synth):
+    """BASELINE config #2 as bench.py runs it: 24 DISTINCT 1280x720 frames (S3 planted, S2 texture, S1 noise
+    mixed) in one batch through the default policy.  Per-window stage-pass counts of every level, raw candidates
+    in canonical order and grouped boxes (order included) of every frame against the oracle."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 24
+    kinds = ["planted", "texture", "noise"]
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, 720, 1280, first=100 + i)[0] for i in range(B)])
+    ctx = pkg.Context(casc)
+    ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)
+    ctx.enable_stage_taps(True)
+    ctx.enable_timing(True)
+    got = ctx.detect_host(frames)
+    ms = ctx.kernel_ms()
+    assert ms["k_pyramid_integral"] > 0.05 and ms["k_integral_rows"] < 0.03 and ms["k_integral_cols"] < 0.03, \
+        "a batch of 24 720p frames must take the fused prep kernel by policy: %r" % ms
+    raws = ctx.raw_candidates(B)
+    want = _oracle_many(oc, frames, True)
+    nlev = len(ctx.levels())
+    assert nlev == 33
+    nboxes = 0
+    for f in range(B):
+        grouped, raw, otaps = want[f]
+        for li in range(nlev):
+            st = ctx.read_tap(f, li, pkg.TAP_STAGES)
+            assert np.array_equal(st, otaps[li]), "frame %d level %d: %d stage counts differ" % (f, li, int((st != otaps[li]).sum()))
+        assert np.array_equal(raws[f], raw), "frame %d raw candidates" % f
+        assert np.array_equal(got[f], grouped), "frame %d boxes" % f
+        nboxes += len(grouped)
+    assert nboxes >= 20
+    # the integrals of one mid-batch frame, largest and a middle level
+    for li in (0, 7):
+        L = ctx.levels()[li]
+        img = oracle.resize_linear_exact(frames[13], L.h, L.w)
+        s, q = oracle.integral(img)
+        assert np.array_equal(ctx.read_tap(13, li, pkg.TAP_SUM), s) and np.array_equal(ctx.read_tap(13, li, pkg.TAP_SQSUM), q)
+
+
+@pytest.mark.parametrize("name", ["alt2", "default", "alt_tree"])
+def test_full_size_2160p_other_cascades(pkg, oracle, synth, name):
+    """BASELINE config #5 (all four cascades at 3840x2160; `alt` is covered in test_gpu_parity.py): raw candidates
+    in canonical order and grouped boxes of one planted 4K frame."""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frame = synth.planted(2160, 3840, synth.frame_seed(3), nfaces=8, min_size=60, max_size=500)[0]
+    ctx = pkg.Context(casc)
+    ctx.configure(2160, 3840, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=1 << 16)
+    assert len(ctx.levels()) == 45
+    assert ctx.algorithmic_bytes() == (440608352 if name == "default" else 303677664)
+    got = ctx.detect_host(frame[None])
+    grouped, raw = oc.detect(frame, 1.1, 2, (30, 30), (0, 0))
+    assert np.array_equal(ctx.raw_candidates(1)[0], raw)
+    assert np.array_equal(got[0], grouped) and len(grouped) >= 4
+
+
+def test_1080p_batch_two_cascades(pkg, oracle, synth):
+    """BASELINE config #3 with a batch > 1: 8 distinct 1920x1080 frames (18 720p-equivalents: fused prep and whole
+    bands by policy) through alt2 and default; stage counts of two frames, raw candidates and boxes of all."""
+    frames = np.stack([synth.make_frames(["planted", "texture"][i % 2], 1, 1080, 1920, first=300 + i)[0] for i in range(8)])
+    for name in ("alt2", "default"):
+        path = oracle.cascade_path(name)
+        casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+        ctx = pkg.Context(casc)
+        ctx.configure(1080, 1920, 1.1, 2, (30, 30), (0, 0), max_batch=8, cand_capacity=1 << 14)
+        ctx.enable_stage_taps(True)
+        got = ctx.detect_host(frames)
+        raws = ctx.raw_candidates(8)
+        want = _oracle_many(oc, frames, True)
+        for f in range(8):
+            grouped, raw, otaps = want[f]
+            if f in (2, 5):
+                for li in range(len(ctx.levels())):
+                    assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (name, f, li)
+            assert np.array_equal(raws[f], raw), (name, f)
+            assert np.array_equal(got[f], grouped), (name, f)
+        ctx.close()
+
+
+def test_one_shard_equals_two_shards(pkg, oracle, synth):
+    """the same frames through 1 vs N shards give identical per-frame lists.  2*B frames as ONE
+    batch of one context, and as two shards (two contexts, B frames each) whose records go through the gather's
+    pack / overflow / unpack path.  minNeighbors 0 returns the raw candidates as boxes, so several frames carry
+    far more than shard.MAX_BOXES rectangles and the overflow block is exercised with real detections."""
+    import importlib
+    shard = importlib.import_module("ugproj_detector_amd.shard")
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 6
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(40 + i), nfaces=3, min_size=40, max_size=110)[0]
+                       for i in range(2 * B)])
+    for mn in (2, 0):
+        one = pkg.Context(casc)
+        one.configure(240, 320, 1.1, mn, (30, 30), (0, 0), max_batch=2 * B, cand_capacity=1 << 14)
+        whole = one.detect_host(frames)
+        merged = {}
+        nover = 0
+        for r in range(2):
+            c = pkg.Context(casc)
+            c.configure(240, 320, 1.1, mn, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 14)
+            boxes = c.detect_host(frames[r * B:(r + 1) * B])
+            ids = list(range(r * B, (r + 1) * B))
+            rec = shard.pack_records(ids, boxes)
+            ov = shard.pack_overflow(boxes)
+            nover += len(ov)
+            assert shard.overflow_counts(rec, 1)[0] == len(ov)
+            for fid, (cnt, b) in shard.unpack_records(rec, [ov]).items():
+                merged[fid] = b
+            c.close()
+        assert sorted(merged) == list(range(2 * B))
+        for f in range(2 * B):
+            assert np.array_equal(merged[f], whole[f]), (mn, f)
+            want, _ = oc.detect(frames[f], 1.1, mn, (30, 30))
+            assert np.array_equal(whole[f], want), (mn, f)
+        if mn == 0:
+            assert nover > 0 and max(len(b) for b in whole) > shard.MAX_BOXES, "stimulus no longer overflows a record"
+        one.close()
+
+
+def _run_bench(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(js) == 1, r.stdout[-2000:]
+    return json.loads(js[0])
+
+
+def test_bench_two_ranks_on_one_gpu(pkg):
+    """`python bench.py --gpus 2` as the driver invokes it (no launcher, no WORLD_SIZE): bench.py spawns its own
+    ranks.  This box has one GPU, so the two ranks share it and the gather runs over gloo (RCCL refuses two ranks
+    on one device); everything else -- frame sharding, record packing, the gather, rank 0 checking frames of BOTH
+    ranks against the oracle before timing -- is the path of the 8-GPU run."""
+    out = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "3", "--warmup", "1", "--batch", "20",
+                      "--cpu-sample", "0"])
+    assert out["n_gpus"] == 2 and out["parity"]["bit_exact"] is True
+    assert out["parity"]["ranks_checked"] == 2 and out["parity"]["gathered_frames"] == 40
+    assert out["value"] > 0 and out["config"]["frames_per_gpu_per_step"] == 20
+
+
+def test_bench_rccl_gather_single_rank(pkg):
+    """The RCCL transport itself on hardware: one rank, process group `nccl`, the record all-gather on its own
+    communication stream with pinned staging (world size 1 is what a one-GPU box can give RCCL)."""
+    out = _run_bench(["--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "20", "--cpu-sample", "0"])
+    assert out["parity"]["bit_exact"] is True and out["parity"]["gathered_frames"] == 20
+    assert "RCCL" in out["config"]["parallelism"] and "roofline" in out

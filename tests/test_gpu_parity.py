@@ -11,12 +11,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _fused_prep_by_default(monkeypatch):
-    """Most tests here run batches of one frame, for which the library would pick the three parallel prep
-    kernels; pin the fused k_pyramid_integral (the throughput path) unless a test chooses otherwise.
-    test_unfused_prep_kernels_agree, the knob test and test_prep_policy_by_batch_size cover the other settings."""
-    monkeypatch.setenv("HC_FUSED_PREP", "1")
+@pytest.fixture(autouse=True, params=["policy", "fused"])
+def prep_route(request, monkeypatch):
+    """Every test of this module runs twice: under the library's own batch-size policy (no environment knob:
+    small batches take the three parallel prep kernels, band segments and the side stream; large ones the fused
+    k_pyramid_integral and whole bands) and with the fused prep kernel pinned (the throughput route, which the
+    mostly single-frame batches here would otherwise never reach).  Tests that set HC_FUSED_PREP themselves
+    override the pin."""
+    monkeypatch.delenv("HC_FUSED_PREP", raising=False)
+    if request.param == "fused":
+        monkeypatch.setenv("HC_FUSED_PREP", "1")
+    return request.param
+
 
 CALL = dict(scale_factor=1.1, min_neighbors=2, min_size=(30, 30))      # reference detector.cc:25-31
 
@@ -274,18 +280,86 @@ def test_device_resident_input(pkg, oracle, synth):
         assert np.array_equal(got[f], want) and np.array_equal(host[f], want)
 
 
-def test_candidate_overflow_is_reported(pkg, oracle, synth):
-    casc = pkg.Cascade(oracle.cascade_path("alt"))
-    fr, _ = synth.planted(240, 320, synth.frame_seed(0), nfaces=3, min_size=40, max_size=110)
+def test_candidate_overflow_grows_and_reruns(pkg, oracle, synth):
+    """A raw-candidate workspace that is too small is not an error the caller sees (OpenCV would simply return more
+    rectangles): the wait grows the buffers to the exact need and runs the batch again.  Batched API with a capacity
+    of 4 candidates, then the synchronous drop-in call on a frame whose minNeighbors-0 output exceeds its default."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(i), nfaces=3, min_size=40, max_size=110)[0] for i in range(3)])
     ctx = pkg.Context(casc)
-    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=4)
-    ctx.enqueue_host(fr[None])
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=3, cand_capacity=4)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    raws = ctx.raw_candidates(3)
+    again = ctx.detect_host(frames)                  # the grown workspace is kept: no second re-run needed
+    for f in range(3):
+        want, raw = oc.detect(frames[f], 1.1, 2, (30, 30))
+        assert len(raw) > 4
+        assert np.array_equal(got[f], want) and np.array_equal(raws[f], raw) and np.array_equal(again[f], want)
+    _check_frame_all_taps(pkg, oracle, ctx, oc, frames[1], 1, 1.1, (30, 30))
+    # device-resident input takes the same route
+    import torch
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    c2 = pkg.Context(casc)
+    c2.configure(240, 320, 1.1, 0, (30, 30), (0, 0), max_batch=3, cand_capacity=8)
+    c2.enqueue_device(d.data_ptr(), 3)
+    got0 = c2.wait(3)
+    for f in range(3):
+        want, _ = oc.detect(frames[f], 1.1, 0, (30, 30))
+        assert np.array_equal(got0[f], want)
+
+
+def test_color_input_is_converted_like_upstream(pkg, oracle, synth):
+    """SURVEY 8b "Semantics": a multi-channel image handed to detectMultiScale is converted with
+    cvtColor(BGR2GRAY) first.  hc_convert_bgr2gray bytes against the oracle (3 and 4 channels, ragged width, row
+    step), then hc_detect_multiscale_image on BGR / BGRA frames against the oracle run on the converted gray."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    bgr, _ = synth.planted_bgr(241, 323, synth.frame_seed(7), nfaces=3, min_size=40, max_size=110)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, (57, 91, 3), dtype=np.uint8)
+    for img in (bgr, noise):
+        want = oracle.bgr2gray(img)
+        assert np.array_equal(pkg.bgr2gray(img), want)
+        bgra = np.concatenate([img, rng.integers(0, 256, img.shape[:2] + (1,), dtype=np.uint8)], axis=2)
+        assert np.array_equal(pkg.bgr2gray(bgra), want)
+        wide = np.zeros((img.shape[0], img.shape[1] + 5, 3), np.uint8)
+        wide[:, :img.shape[1]] = img
+        assert np.array_equal(pkg.bgr2gray(wide[:, :img.shape[1]]), want)          # row step > row bytes
+    gray = oracle.bgr2gray(bgr)
+    want, _ = oc.detect(gray, 1.1, 2, (30, 30))
+    assert len(want) > 0
+    assert np.array_equal(casc.detect_multiscale(bgr, **CALL), want)
+    bgra = np.concatenate([bgr, np.full(bgr.shape[:2] + (1,), 255, np.uint8)], axis=2)
+    assert np.array_equal(casc.detect_multiscale(bgra, **CALL), want)
+    assert np.array_equal(casc.detect_multiscale(gray, **CALL), want)              # and the plain gray call after it
+
+
+@pytest.mark.parametrize("src,scan", [((720, 1280), (405, 720)), ((480, 854), (360, 640)), ((500, 700), (360, 640))])
+def test_scan_resize_any_ratio(pkg, oracle, synth, src, scan):
+    """reference src/tracker/face_tracker.cc:112-114 resizes to whatever `scan.frame_size` says: INTER_AREA with
+    non-integer ratios (equal and unequal in x and y) on device against the oracle, then detectFaces on the result."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted_bgr(src[0], src[1], synth.frame_seed(60 + i), nfaces=5, min_size=80, max_size=220)[0]
+                       for i in range(2)])
+    ctx = pkg.Context(casc)
+    ctx.configure(scan[0], scan[1], 1.1, 2, (30, 30), (0, 0), max_batch=2, cand_capacity=1 << 14)
+    ctx.enable_faces()
+    ctx.enable_scan_resize(src[0], src[1])
+    got = ctx.faces_host(frames)
+    for f in range(2):
+        small = oracle.resize_area(frames[f], scan[0], scan[1])
+        assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_BGR), small)
+        want, mask, gray = oc.detect_faces(small, want_taps=True)
+        assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_MASK), mask)
+        assert np.array_equal(ctx.read_face_tap(f, pkg.TAP_FACE_GRAY), gray)
+        assert np.array_equal(got[f], want)
     with pytest.raises(pkg.HipCascadeError) as e:
-        ctx.wait(1)
-    assert e.value.code == -8                      # HC_ERR_CAND_OVERFLOW: loud, never silently truncated
-    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=4096)
-    want, _ = oracle.OracleCascade(oracle.cascade_path("alt")).detect(fr, 1.1, 2, (30, 30))
-    assert np.array_equal(ctx.detect_host(fr[None])[0], want)
+        ctx.enable_scan_resize(scan[0] - 1, src[1])          # enlarging in y: not INTER_AREA's shrinking path
+    assert e.value.code == -4
 
 
 def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf):
@@ -488,9 +562,7 @@ def test_config1_plumbing_scan_resize_then_detect_faces(pkg, oracle, synth):
             assert np.array_equal(got[f], want)
             n += len(want)
         assert n > 0
-    with pytest.raises(pkg.HipCascadeError) as e:
-        ctx.enable_scan_resize(700, 1280)           # 700/360 is not an integer factor
-    assert e.value.code == -4
+    ctx.enable_scan_resize(700, 1280)               # 700/360 is not an integer factor: the general path takes it
 
 
 def test_randomised_calls_match_oracle(pkg, oracle, synth):

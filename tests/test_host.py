@@ -167,3 +167,45 @@ def test_cpp_shim_builds_and_reports_errors(pkg, oracle, tmp_path):
     np.zeros((64, 64), np.uint8).tofile(fr)
     r = subprocess.run([demo, str(tmp_path / "nope.xml"), str(fr), "64", "64"], capture_output=True, text=True)
     assert r.returncode == 1 and "cannot load cascade" in r.stderr
+
+
+def test_box_file_through_the_c_abi(pkg, tmp_path):
+    """SURVEY 8f-4 for the C++ side: hc_boxes_save / hc_boxes_load write and read the very bytes of
+    ugproj-detector_amd/shard.py's HCBX format, so the C++ tracker can consume what a Python / multi-GPU run wrote
+    and vice versa (reference src/tracker/face_tracker.cc:294-302 consumes every box of every frame in order)."""
+    import importlib
+    shard = importlib.import_module("ugproj_detector_amd.shard")
+    boxes = {7: np.array([[1, 2, 30, 30]], np.int32), 3: np.zeros((0, 4), np.int32),
+             11: np.arange(4 * 100, dtype=np.int32).reshape(100, 4), 2_000_000: np.array([[-5, 0, 9, 9], [1, 1, 1, 1]], np.int32)}
+    a, b = str(tmp_path / "c.hcbx"), str(tmp_path / "py.hcbx")
+    pkg.save_boxes(a, boxes)                 # C ABI writer (frames handed over in dict order, stored in ascending id)
+    shard.save_boxes(b, boxes)               # Python writer
+    assert open(a, "rb").read() == open(b, "rb").read()
+    for path in (a, b):
+        got = pkg.load_boxes(path)           # C ABI reader
+        assert list(got) == sorted(boxes)
+        for k in boxes:
+            assert got[k].tolist() == boxes[k].tolist()
+    assert {k: v.tolist() for k, v in shard.load_boxes(a).items()} == {k: v.tolist() for k, v in boxes.items()}
+    # empty file, size query, too-small buffers, malformed input, duplicate ids
+    e = str(tmp_path / "empty.hcbx")
+    pkg.save_boxes(e, {})
+    assert pkg.load_boxes(e) == {}
+    import ctypes as C
+    nf, nr = C.c_int(), C.c_int()
+    assert pkg.lib.hc_boxes_load(a.encode(), None, None, 0, None, 0, C.byref(nf), C.byref(nr)) == 0
+    assert (nf.value, nr.value) == (4, 103)
+    ids = np.zeros(2, np.int32)
+    ofs = np.zeros(3, np.int32)
+    rects = np.zeros((103, 4), np.int32)
+    rc = pkg.lib.hc_boxes_load(a.encode(), ids.ctypes.data, ofs.ctypes.data, 2, rects.ctypes.data, 103, C.byref(nf), C.byref(nr))
+    assert rc == -7 and (nf.value, nr.value) == (4, 103)               # HC_ERR_CAPACITY, sizes still reported
+    raw = open(a, "rb").read()
+    for bad in (b"nope", raw[:10], raw[:-3], raw[:12]):
+        (tmp_path / "bad").write_bytes(bad)
+        rc = pkg.lib.hc_boxes_load(str(tmp_path / "bad").encode(), None, None, 0, None, 0, C.byref(nf), C.byref(nr))
+        assert rc == -2, bad[:12]                                       # HC_ERR_FORMAT
+    assert pkg.lib.hc_boxes_load(str(tmp_path / "missing").encode(), None, None, 0, None, 0, C.byref(nf), C.byref(nr)) == -1
+    dup_ids = np.array([5, 5], np.int32)
+    dofs = np.array([0, 0, 0], np.int32)
+    assert pkg.lib.hc_boxes_save(str(tmp_path / "dup").encode(), 2, dup_ids.ctypes.data, dofs.ctypes.data, None) == -3

@@ -65,6 +65,13 @@ _SIGS = {
     "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.POINTER(C.c_int)]),
+    "hc_detect_multiscale_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
+                                             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                             C.POINTER(C.c_int)]),
+    "hc_convert_bgr2gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "hc_boxes_save": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hc_boxes_load": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                C.POINTER(C.c_int)]),
     "hc_context_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hc_context_destroy": (None, [C.c_void_p]),
     "hc_context_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
@@ -170,8 +177,18 @@ class Cascade:
                           capacity=4096):
         """detectMultiScale(image, scaleFactor, minNeighbors, flags, minSize, maxSize) -> (K,4) int32 x,y,w,h."""
         gray = np.asarray(gray)
+        if gray.dtype == np.uint8 and gray.ndim == 3 and gray.shape[2] in (3, 4) and gray.strides[2] == 1 and \
+                gray.strides[1] == gray.shape[2]:
+            # multi-channel input: upstream converts BGR(A) -> gray inside detectMultiScale
+            out = np.zeros((capacity, 4), np.int32)
+            n = C.c_int()
+            _check(lib.hc_detect_multiscale_image(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.shape[2],
+                                                  gray.strides[0], scale_factor, min_neighbors, flags, min_size[0],
+                                                  min_size[1], max_size[0], max_size[1], out.ctypes.data, capacity,
+                                                  C.byref(n)))
+            return out[:n.value].copy()
         if gray.dtype != np.uint8 or gray.ndim != 2 or gray.strides[1] != 1:
-            raise ValueError("need a 2-D uint8 image with unit column stride")
+            raise ValueError("need a 2-D uint8 image with unit column stride (or HxWx3 / HxWx4 packed BGR / BGRA)")
         out = np.zeros((capacity, 4), np.int32)
         n = C.c_int()
         _check(lib.hc_detect_multiscale(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
@@ -298,6 +315,39 @@ class Context:
         if a.size:
             _check(lib.hc_context_read_tap(self._h, frame, level_index, what, a.ctypes.data, a.nbytes))
         return a
+
+
+def bgr2gray(img):
+    """cvtColor(img, COLOR_BGR2GRAY) on the device (hc_convert_bgr2gray): HxWx3 / HxWx4 uint8 -> HxW uint8"""
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] not in (3, 4) or img.strides[2] != 1 or img.strides[1] != img.shape[2]:
+        raise ValueError("need an HxWx3 / HxWx4 uint8 image with packed pixels")
+    g = np.zeros(img.shape[:2], np.uint8)
+    _check(lib.hc_convert_bgr2gray(img.ctypes.data, img.shape[0], img.shape[1], img.shape[2], img.strides[0], g.ctypes.data,
+                                   g.strides[0]))
+    return g
+
+
+def save_boxes(path, boxes_by_frame):
+    """HCBX box file through the C ABI (hc_boxes_save): dict frame_id -> (K,4) int array"""
+    ids = np.array(list(boxes_by_frame), np.int32)
+    lists = [np.asarray(boxes_by_frame[int(i)], np.int32).reshape(-1, 4) for i in ids]
+    ofs = np.zeros(len(ids) + 1, np.int32)
+    ofs[1:] = np.cumsum([len(b) for b in lists])
+    rects = np.ascontiguousarray(np.concatenate(lists) if lists else np.zeros((0, 4), np.int32))
+    _check(lib.hc_boxes_save(os.fsencode(path), len(ids), ids.ctypes.data, ofs.ctypes.data, rects.ctypes.data))
+
+
+def load_boxes(path):
+    """HCBX box file through the C ABI (hc_boxes_load) -> dict frame_id -> (K,4) int32, ascending frame id"""
+    nf, nr = C.c_int(), C.c_int()
+    _check(lib.hc_boxes_load(os.fsencode(path), None, None, 0, None, 0, C.byref(nf), C.byref(nr)))     # size query
+    ids = np.zeros(nf.value, np.int32)
+    ofs = np.zeros(nf.value + 1, np.int32)
+    rects = np.zeros((max(nr.value, 1), 4), np.int32)
+    _check(lib.hc_boxes_load(os.fsencode(path), ids.ctypes.data, ofs.ctypes.data, nf.value, rects.ctypes.data, nr.value,
+                             C.byref(nf), C.byref(nr)))
+    return {int(ids[i]): rects[ofs[i]:ofs[i + 1]].copy() for i in range(nf.value)}
 
 
 def group_rectangles(rects, group_threshold, eps=0.2):

@@ -4,16 +4,33 @@
 //   k_equalize_lut     equalizeHist's lookup table from the histogram (one workgroup per frame)
 //   k_apply_lut_mask   gray = lut[gray] & mask        (equalizeHist; gray &= mask)
 //   k_box_mask_sums    sum of the mask inside every detected rect, from the mask's integral image
-// 8-bit OpenCV semantics per SURVEY.md A.13: 14-bit fixed-point colour coefficients with
-// round-to-nearest descale; equalizeHist scale = 255.f / (total - hist[first]) in f32,
-// lut = saturate(cvRound(sum * scale)).  Integer work is exact; the two f32 operations are IEEE
-// single ops (file compiled with -ffp-contract=off).
+//   k_bgr2gray        cvtColor(BGR2GRAY / BGRA2GRAY) alone: what detectMultiScale applies to a colour image
+//   k_area_decimate / k_area_resize   cv::resize(INTER_AREA) of the tracker's scan-size step
+// 8-bit OpenCV semantics per SURVEY.md A.13 (colour constants revised in round 2): BGR2YCrCb uses the
+// 14-bit coefficient set (yuv_shift = 14), BGR2GRAY the 15-bit set RY15/GY15/BY15 (gray_shift = 15) of
+// OpenCV >= 4, both with round-to-nearest descale; equalizeHist scale = 255.f / (total - hist[first]) in
+// f32, lut = saturate(cvRound(sum * scale)).  Integer work is exact; the f32 operations are IEEE single
+// ops in upstream's order (file compiled with -ffp-contract=off).  Parity of these constants is unpinned.
 #include <hip/hip_runtime.h>
 
 #include "device_types.h"
 #include "kernels.h"
 
 namespace hc {
+
+// COLOR_BGR2GRAY, 8-bit: RY15 = 9798, GY15 = 19235, BY15 = 3735, gray_shift = 15
+__device__ __forceinline__ int gray15(int b, int g, int r) { return (b * 3735 + g * 19235 + r * 9798 + (1 << 14)) >> 15; }
+
+// gray plane of a 3- or 4-channel 8-bit image (BGR / BGRA; alpha ignored)
+__global__ __launch_bounds__(WG_THREADS) void k_bgr2gray(const uint8_t* __restrict__ src, size_t frame_stride, size_t row_step,
+                                                         int channels, int rows, int cols, uint8_t* __restrict__ gray,
+                                                         size_t plane_stride) {
+  const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int y = i / cols, x = i - y * cols;
+  const uint8_t* p = src + (size_t)blockIdx.y * frame_stride + (size_t)y * row_step + (size_t)channels * x;
+  gray[(size_t)blockIdx.y * plane_stride + i] = (uint8_t)gray15(p[0], p[1], p[2]);
+}
 
 __global__ __launch_bounds__(WG_THREADS) void k_skin_gray(const uint8_t* __restrict__ bgr, size_t frame_stride,
                                                           size_t row_step, int rows, int cols, SkinBounds sb,
@@ -28,13 +45,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_skin_gray(const uint8_t* __restr
     const int y = i / cols, x = i - y * cols;
     const uint8_t* p = bgr + (size_t)frame * frame_stride + (size_t)y * row_step + 3 * (size_t)x;
     const int b = p[0], g = p[1], r = p[2];
-    const int Y = (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;                  // == cvtColor(BGR2GRAY)
+    const int Y = (b * 1868 + g * 9617 + r * 4899 + 8192) >> 14;                  // Y of cvtColor(BGR2YCrCb)
+    const int G = gray15(b, g, r);                                                 // cvtColor(BGR2GRAY)
     const int Cr = min(max(((r - Y) * 11682 + (128 << 14) + 8192) >> 14, 0), 255);
     const int Cb = min(max(((b - Y) * 9241 + (128 << 14) + 8192) >> 14, 0), 255);
     const bool in = Y >= sb.lo[0] && Y <= sb.hi[0] && Cr >= sb.lo[1] && Cr <= sb.hi[1] && Cb >= sb.lo[2] && Cb <= sb.hi[2];
-    gray[(size_t)frame * plane_stride + i] = (uint8_t)Y;
+    gray[(size_t)frame * plane_stride + i] = (uint8_t)G;
     mask[(size_t)frame * plane_stride + i] = in ? 255 : 0;
-    atomicAdd(&h[Y], 1u);
+    atomicAdd(&h[G], 1u);
   }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&hist[(size_t)frame * 256 + threadIdx.x], h[threadIdx.x]);
@@ -109,6 +127,35 @@ __global__ __launch_bounds__(WG_THREADS) void k_area_decimate(const uint8_t* __r
   dst[(size_t)blockIdx.y * dst_frame_stride + i] = (uint8_t)min(v, 255);
 }
 
+// cv::resize(INTER_AREA), general shrinking ratio (resizeArea_<uchar, float>): one thread per destination byte.
+// Taps of destination column x: xofs[x] .. xofs[x+1] into (xsi, xal); rows likewise.  f32 accumulation in tap
+// order, exactly upstream's operation sequence: buf = ((0 + S0*a0) + S1*a1) + ..; sum = b0*buf0, += b1*buf1, ..
+__global__ __launch_bounds__(WG_THREADS) void k_area_resize(const uint8_t* __restrict__ src, size_t src_frame_stride,
+                                                            size_t src_row_step, int channels, const int* __restrict__ xofs,
+                                                            const int* __restrict__ xsi, const float* __restrict__ xal,
+                                                            const int* __restrict__ yofs, const int* __restrict__ ysi,
+                                                            const float* __restrict__ yal, uint8_t* __restrict__ dst,
+                                                            size_t dst_frame_stride, int drows, int dcols) {
+  const int i = blockIdx.x * WG_THREADS + threadIdx.x;
+  const int rowb = dcols * channels;
+  if (i >= drows * rowb) return;
+  const int y = i / rowb, xb = i - y * rowb, x = xb / channels, ch = xb - x * channels;
+  const uint8_t* base = src + (size_t)blockIdx.y * src_frame_stride + ch;
+  const int k0 = xofs[x], k1 = xofs[x + 1], j0 = yofs[y], j1 = yofs[y + 1];
+  float sum = 0.f;
+  for (int j = j0; j < j1; j++) {
+    const uint8_t* S = base + (size_t)ysi[j] * src_row_step;
+    float buf = 0.f;
+    for (int k = k0; k < k1; k++) {
+      const float t = (float)S[(size_t)xsi[k] * channels] * xal[k];
+      buf = buf + t;
+    }
+    const float t = yal[j] * buf;
+    sum = (j == j0) ? t : sum + t;
+  }
+  dst[(size_t)blockIdx.y * dst_frame_stride + i] = (uint8_t)min(max(__float2int_rn(sum), 0), 255);
+}
+
 // sums[i] = sum of mask over rect i, from the (rows+1) x pitch integral of the mask
 __global__ void k_box_mask_sums(const uint32_t* __restrict__ integ, size_t int_stride, int pitch, const int* __restrict__ boxes,
                                 int nboxes, uint32_t* __restrict__ sums) {
@@ -146,6 +193,28 @@ int launch_area_decimate(hipStream_t st, int nframes, const uint8_t* src, size_t
   const int n = drows * dcols * channels;
   hipLaunchKernelGGL(k_area_decimate, dim3((n + WG_THREADS - 1) / WG_THREADS, nframes), dim3(WG_THREADS), 0, st, src,
                      src_frame_stride, src_row_step, channels, fx, fy, dst, dst_frame_stride, drows, dcols);
+  HC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_area_resize(hipStream_t st, int nframes, const uint8_t* src, size_t src_frame_stride, size_t src_row_step,
+                       int channels, const int* xofs, const int* xsi, const float* xal, const int* yofs, const int* ysi,
+                       const float* yal, uint8_t* dst, size_t dst_frame_stride, int drows, int dcols) {
+  if (nframes == 0) return 0;
+  const int n = drows * dcols * channels;
+  hipLaunchKernelGGL(k_area_resize, dim3((n + WG_THREADS - 1) / WG_THREADS, nframes), dim3(WG_THREADS), 0, st, src,
+                     src_frame_stride, src_row_step, channels, xofs, xsi, xal, yofs, ysi, yal, dst, dst_frame_stride,
+                     drows, dcols);
+  HC_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_bgr2gray(hipStream_t st, int nframes, const uint8_t* src, size_t frame_stride, size_t row_step, int channels,
+                    int rows, int cols, uint8_t* gray, size_t plane_stride) {
+  if (nframes == 0) return 0;
+  const int npix = rows * cols;
+  hipLaunchKernelGGL(k_bgr2gray, dim3((npix + WG_THREADS - 1) / WG_THREADS, nframes), dim3(WG_THREADS), 0, st, src,
+                     frame_stride, row_step, channels, rows, cols, gray, plane_stride);
   HC_LAUNCH_CHECK();
   return 0;
 }

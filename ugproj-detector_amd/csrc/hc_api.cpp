@@ -136,6 +136,7 @@ struct hc_context {
   hc::Plan plan;
   bool configured = false;
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
+  size_t cand_cap = 0;                   // raw-candidate capacity of d_cand / h_cand for a whole batch (grows on demand)
   // cascade-kernel tiling per ystep class (index 0: ystep 1, index 1: ystep 2)
   int band_rows[2] = {16, 16};
   int band_waves[2] = {4, 8};            // wavefronts per cascade workgroup (4 or 8); measured best on MI355X
@@ -151,9 +152,12 @@ struct hc_context {
   int row_stages = 1;
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
 
-  // device
+  // device.  d_frames, d_color, d_pyr and d_taps are allocated on first use: the device-resident
+  // throughput path needs none of them (two 3840x2160 contexts would not fit otherwise)
   uint8_t* d_frames = nullptr;   // staging for the host-input path
-  uint8_t* d_pyr = nullptr;
+  uint8_t* d_color = nullptr;    // staging for multi-channel input to detectMultiScale (BGR / BGRA)
+  size_t color_bytes = 0;
+  uint8_t* d_pyr = nullptr;      // pyramid bytes: the unfused prep kernels and the debug tap
   uint32_t* d_sum = nullptr;
   uint32_t* d_sq = nullptr;
   float* d_vnf = nullptr;
@@ -192,10 +196,17 @@ struct hc_context {
   // decimated by INTER_AREA to the configured rows x cols before detectFaces
   int src_rows = 0, src_cols = 0;
   uint8_t* d_src_bgr = nullptr;
+  bool area_general = false;              // non-integer ratio: tap tables instead of the box kernel
+  int *d_area_xofs = nullptr, *d_area_xsi = nullptr, *d_area_yofs = nullptr, *d_area_ysi = nullptr;
+  float *d_area_xal = nullptr, *d_area_yal = nullptr;
   size_t mask_int_words = 0;
 
   int pending = 0;               // frames enqueued and not yet waited
   int last_frames = 0;
+  // the batch in flight, remembered so that hc_detect_batch_wait can run it again after growing the
+  // candidate workspace (the caller keeps its frames valid until the wait returns)
+  const uint8_t* inflight_src = nullptr;
+  size_t inflight_frame_stride = 0, inflight_row_step = 0;
   bool taps_enabled = false, timing_enabled = false, timed_last = false;
   hipEvent_t ev[HC_NKERNELS + 1] = {};
   float last_ms[HC_NKERNELS] = {};
@@ -205,11 +216,12 @@ struct hc_context {
   int host_threads = 4;   // 1 thread already hides the 64-frame grouping under the next batch (tools/exp_host_threads.sh)
 
   void free_workspace() {
-    void* ptrs[] = {d_frames, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
+    void* ptrs[] = {d_frames, d_color, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
                     d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_seg_items[0], d_seg_items[1], d_cand,
-                    d_count};
+                    d_count, d_area_xofs, d_area_xsi, d_area_xal, d_area_yofs, d_area_ysi, d_area_yal};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    d_frames = d_pyr = nullptr; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
+    d_frames = d_color = d_pyr = nullptr; color_bytes = 0;
+    d_area_xofs = d_area_xsi = d_area_yofs = d_area_ysi = nullptr; d_area_xal = d_area_yal = nullptr; area_general = false; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
     d_xtab = d_ytab = nullptr;
     d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items[0] = d_band_items[1] = nullptr;
     d_seg_items[0] = d_seg_items[1] = nullptr;
@@ -393,10 +405,32 @@ hc_level to_public(const hc::DevLevel& L) {
   return o;
 }
 
+// first-use allocations (outside the steady state: a context that has run one batch of a kind never allocates again)
+int ensure_frames(hc_context* c) {
+  if (c->d_frames) return HC_OK;
+  return dev_alloc(&c->d_frames, (size_t)c->max_batch * c->plan.rows * c->plan.cols);
+}
+int ensure_pyr(hc_context* c) {
+  if (c->d_pyr) return HC_OK;
+  return dev_alloc(&c->d_pyr, (size_t)c->max_batch * c->plan.pyr_bytes);
+}
+int ensure_taps(hc_context* c) {
+  if (c->d_taps) return HC_OK;
+  return dev_alloc(&c->d_taps, (size_t)c->max_batch * c->plan.grid_elems);
+}
+
 int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, size_t row_step, int nframes) {
   const hc::Plan& P = c->plan;
   const hc::Model& m = c->casc->model;
   hipStream_t s = c->stream;
+  c->inflight_src = d_frames; c->inflight_frame_stride = frame_stride; c->inflight_row_step = row_step;
+  {
+    const double equiv0 = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
+    const bool fused0 = c->fused_prep > 0 || (c->fused_prep < 0 && equiv0 > c->fused_min_batch);
+    int rc0;
+    if (!P.levels.empty() && (c->taps_enabled || !fused0) && (rc0 = ensure_pyr(c))) return rc0;
+    if (!P.levels.empty() && c->taps_enabled && (rc0 = ensure_taps(c))) return rc0;
+  }
   HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), s));
   const bool timed = c->timing_enabled;
   c->timed_last = timed;
@@ -454,7 +488,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.sparse_max = c->sparse_max;
       A.row_stages = c->row_stages;
       A.cand = c->d_cand; A.cand_count = c->d_count;
-      A.cand_cap = (unsigned int)((size_t)c->cand_per_frame * c->max_batch);
+      A.cand_cap = (unsigned int)c->cand_cap;
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
       e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
@@ -630,13 +664,11 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   ctx->min_neighbors = min_neighbors;
   ctx->cand_per_frame = cand_capacity > 0 ? cand_capacity : 4096;
   const size_t B = (size_t)max_batch;
-  if ((rc = dev_alloc(&ctx->d_frames, B * rows * cols))) return rc;
-  if ((rc = dev_alloc(&ctx->d_pyr, B * P.pyr_bytes))) return rc;
   if ((rc = dev_alloc(&ctx->d_sum, B * P.int_words))) return rc;
   if ((rc = dev_alloc(&ctx->d_sq, B * P.int_words))) return rc;
   if ((rc = dev_alloc(&ctx->d_vnf, B * P.grid_elems))) return rc;
-  if ((rc = dev_alloc(&ctx->d_taps, B * P.grid_elems))) return rc;
-  if ((rc = dev_alloc(&ctx->d_cand, B * ctx->cand_per_frame))) return rc;
+  ctx->cand_cap = B * ctx->cand_per_frame;
+  if ((rc = dev_alloc(&ctx->d_cand, ctx->cand_cap))) return rc;
   if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
   // row 0 / column 0 of every integral stay zero for the lifetime of the workspace
   HIPCHK(hipMemset(ctx->d_sum, 0, std::max<size_t>(B * P.int_words, 1) * 4));
@@ -661,7 +693,7 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
     ctx->n_seg_items[k] = (int)seg.size();
     if ((rc = dev_upload(&ctx->d_seg_items[k], seg))) return rc;
   }
-  HIPCHK(hipHostMalloc((void**)&ctx->h_cand, B * ctx->cand_per_frame * sizeof(unsigned long long), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->h_cand, ctx->cand_cap * sizeof(unsigned long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
   ctx->pending = 0;
   ctx->last_frames = 0;
@@ -686,6 +718,7 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
+  if (int rc = ensure_frames(ctx)) return rc;
   const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
   if (row_step_bytes == cols && (nframes == 1 || frame_stride_bytes == rows * cols)) {
     HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, (size_t)nframes * rows * cols, hipMemcpyHostToDevice, ctx->stream));
@@ -728,16 +761,34 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   HIPCHK(hipSetDevice(ctx->device));
   const int nframes = ctx->pending;
   ctx->pending = 0;
-  HIPCHK(hipStreamSynchronize(ctx->copy_stream));     // this batch's kernels + count copy are done
+  unsigned int count = 0;
+  for (int attempt = 0;; attempt++) {
+    HIPCHK(hipStreamSynchronize(ctx->copy_stream));     // this batch's kernels + count copy are done
+    count = *ctx->h_count;
+    if (ctx->debug_max_stages > 0 && count > ctx->cand_cap) count = 0;   // timing experiments only
+    if (count <= ctx->cand_cap) break;
+    // More raw candidates than the workspace holds (the counter keeps counting past the capacity, so the need is
+    // known exactly).  OpenCV would simply return more rectangles: grow the buffers and run the batch again.
+    if (attempt >= 2 || !ctx->inflight_src)
+      return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow and the batch cannot be re-run");
+    const size_t want = (size_t)count + (size_t)count / 4 + 1024;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_cand); ctx->d_cand = nullptr;
+    (void)hipHostFree(ctx->h_cand); ctx->h_cand = nullptr;
+    ctx->cand_cap = 0;
+    int rc = dev_alloc(&ctx->d_cand, want);
+    if (rc) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing it failed: " + g_err);
+    if (hipHostMalloc((void**)&ctx->h_cand, want * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+      return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing the host buffer failed");
+    ctx->cand_cap = want;
+    if ((rc = enqueue_device(ctx, ctx->inflight_src, ctx->inflight_frame_stride, ctx->inflight_row_step, nframes))) return rc;
+    ctx->pending = 0;
+  }
   if (ctx->timed_last && !ctx->plan.levels.empty())
     for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
-  unsigned int count = *ctx->h_count;
-  if (ctx->debug_max_stages > 0 && count > (size_t)ctx->cand_per_frame * ctx->max_batch) count = 0;   // timing experiments only
-  const size_t cap = (size_t)ctx->cand_per_frame * ctx->max_batch;
   ctx->last_frames = nframes;
   ctx->last_raw.clear();
   ctx->last_raw_ofs.assign(nframes + 1, 0);
-  if (count > cap) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; raise cand_capacity");
   if (count) {
     HIPCHK(hipMemcpyAsync(ctx->h_cand, ctx->d_cand, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                           ctx->copy_stream));
@@ -853,13 +904,27 @@ int hc_context_enable_faces(hc_context* ctx) {
 
 int hc_context_enable_scan_resize(hc_context* ctx, int src_rows, int src_cols) {
   if (!ctx || !ctx->configured || !ctx->faces_enabled) return set_err(HC_ERR_STATE, "call hc_context_enable_faces first");
-  if (src_rows <= 0 || src_cols <= 0 || src_rows % ctx->plan.rows || src_cols % ctx->plan.cols)
-    return set_err(HC_ERR_UNSUPPORTED, "INTER_AREA scan resize supports integer decimation factors only");
+  if (src_rows < ctx->plan.rows || src_cols < ctx->plan.cols)
+    return set_err(HC_ERR_UNSUPPORTED, "INTER_AREA scan resize: the scan size must not exceed the source size in either axis");
   HIPCHK(hipSetDevice(ctx->device));
-  if (ctx->d_src_bgr) (void)hipFree(ctx->d_src_bgr);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  void* old[] = {ctx->d_src_bgr, ctx->d_area_xofs, ctx->d_area_xsi, ctx->d_area_xal, ctx->d_area_yofs, ctx->d_area_ysi, ctx->d_area_yal};
+  for (void* p : old) if (p) (void)hipFree(p);
   ctx->d_src_bgr = nullptr;
+  ctx->d_area_xofs = ctx->d_area_xsi = ctx->d_area_yofs = ctx->d_area_ysi = nullptr; ctx->d_area_xal = ctx->d_area_yal = nullptr;
   int rc = dev_alloc(&ctx->d_src_bgr, (size_t)ctx->max_batch * src_rows * src_cols * 3);
   if (rc) return rc;
+  // cv::resize: the box kernel when both ratios are integers (resizeAreaFast_), tap tables otherwise (resizeArea_)
+  ctx->area_general = (src_rows % ctx->plan.rows) != 0 || (src_cols % ctx->plan.cols) != 0;
+  if (ctx->area_general) {
+    std::vector<int> xo, xs, yo, ysv;
+    std::vector<float> xa, ya;
+    hc::build_area_table(src_cols, ctx->plan.cols, xo, xs, xa);
+    hc::build_area_table(src_rows, ctx->plan.rows, yo, ysv, ya);
+    if ((rc = dev_upload(&ctx->d_area_xofs, xo)) || (rc = dev_upload(&ctx->d_area_xsi, xs)) || (rc = dev_upload(&ctx->d_area_xal, xa)) ||
+        (rc = dev_upload(&ctx->d_area_yofs, yo)) || (rc = dev_upload(&ctx->d_area_ysi, ysv)) || (rc = dev_upload(&ctx->d_area_yal, ya)))
+      return rc;
+  }
   ctx->src_rows = src_rows;
   ctx->src_cols = src_cols;
   return HC_OK;
@@ -869,9 +934,13 @@ static int faces_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_str
                          const int lower[3], const int upper[3]) {
   if (ctx->src_rows) {   // cv::resize(orig, curr, scan.frame_size, 0, 0, INTER_AREA) first
     const size_t drow = (size_t)ctx->plan.cols * 3, dframe = drow * ctx->plan.rows;
-    int e = hc::launch_area_decimate(ctx->stream, nframes, d_bgr, frame_stride, row_step, 3, ctx->src_cols / ctx->plan.cols,
-                                     ctx->src_rows / ctx->plan.rows, ctx->d_bgr, dframe, ctx->plan.rows, ctx->plan.cols);
-    if (e) return set_err(HC_ERR_HIP, std::string("k_area_decimate launch: ") + hipGetErrorString((hipError_t)e));
+    int e = ctx->area_general
+                ? hc::launch_area_resize(ctx->stream, nframes, d_bgr, frame_stride, row_step, 3, ctx->d_area_xofs, ctx->d_area_xsi,
+                                         ctx->d_area_xal, ctx->d_area_yofs, ctx->d_area_ysi, ctx->d_area_yal, ctx->d_bgr, dframe,
+                                         ctx->plan.rows, ctx->plan.cols)
+                : hc::launch_area_decimate(ctx->stream, nframes, d_bgr, frame_stride, row_step, 3, ctx->src_cols / ctx->plan.cols,
+                                           ctx->src_rows / ctx->plan.rows, ctx->d_bgr, dframe, ctx->plan.rows, ctx->plan.cols);
+    if (e) return set_err(HC_ERR_HIP, std::string("INTER_AREA launch: ") + hipGetErrorString((hipError_t)e));
     d_bgr = ctx->d_bgr; frame_stride = dframe; row_step = drow;
   }
   hc::SkinBounds sb{};
@@ -962,29 +1031,23 @@ int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t
   return emit(grouped, out, out_capacity, offsets);
 }
 
+}  // extern "C"
+namespace {
+int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min_neighbors, int min_w, int min_h, int max_w,
+                 int max_h, hc_context** out);
+}
+extern "C" {
+
 int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols, size_t step_bytes, const int lower[3],
                     const int upper[3], double scale_factor, hc_rect* out, int out_capacity, int* out_count) {
   if (!c || !bgr || !lower || !upper || !out_count) return set_err(HC_ERR_ARG, "null argument");
   if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
   *out_count = 0;
   std::lock_guard<std::mutex> lock(c->mu);
-  int dev = 0, ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
-  HIPCHK(hipGetDevice(&dev));
-  hc_context* ctx = c->default_ctx;
-  if (ctx && ctx->device != dev) { hc_context_destroy(ctx); ctx = c->default_ctx = nullptr; }
-  int rc;
-  if (!ctx) {
-    if ((rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
-    c->default_ctx = ctx;
-  }
-  const hc::Plan& P = ctx->plan;
+  hc_context* ctx = nullptr;
   // the reference's literals: minNeighbors 2, minSize 30x30, maxSize unset (detector.cc:28-31)
-  if (!ctx->configured || P.rows != rows || P.cols != cols || P.scale_factor != scale_factor || P.min_w != 30 ||
-      P.min_h != 30 || P.max_w != cols || P.max_h != rows || ctx->min_neighbors != 2) {
-    if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, 2, 30, 30, 0, 0, 1, 1 << 16))) return rc;
-  }
+  int rc = sync_context(c, rows, cols, scale_factor, 2, 30, 30, 0, 0, &ctx);
+  if (rc) return rc;
   if ((rc = hc_context_enable_faces(ctx))) return rc;
   if ((rc = hc_faces_batch_enqueue_host(ctx, bgr, 0, step_bytes, 1, lower, upper))) return rc;
   int32_t ofs[2] = {0, 0};
@@ -1056,6 +1119,7 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
     case HC_TAP_PYRAMID: {
       const size_t n = (size_t)L.w * L.h;
       if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+      if (!ctx->d_pyr) return set_err(HC_ERR_STATE, "no pyramid was materialised: enable stage taps before the enqueue");
       HIPCHK(hipMemcpy(dst, ctx->d_pyr + (size_t)frame * P.pyr_bytes + L.pyr_ofs, n, hipMemcpyDeviceToHost));
       return HC_OK;
     }
@@ -1074,7 +1138,7 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
       return HC_OK;
     }
     case HC_TAP_STAGES: {
-      if (!ctx->taps_enabled) return set_err(HC_ERR_STATE, "stage taps were not enabled");
+      if (!ctx->taps_enabled || !ctx->d_taps) return set_err(HC_ERR_STATE, "stage taps were not enabled");
       const size_t n = (size_t)L.nx * L.ny_all;
       if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
       if (n) HIPCHK(hipMemcpy(dst, ctx->d_taps + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
@@ -1115,16 +1179,13 @@ int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]) {
 
 // ---- synchronous single-frame call: the literal replacement of
 //      cascade.detectMultiScale(gray, faces, scale, 2, 0|CASCADE_SCALE_IMAGE, Size(30,30))
-int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,
-                         int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h, hc_rect* out,
-                         int out_capacity, int* out_count) {
-  (void)flags;   // ignored by the OpenCV >= 4 evaluation path for this cascade format (SURVEY A.0)
-  if (!c || !gray || !out_count) return set_err(HC_ERR_ARG, "null argument");
-  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
-  *out_count = 0;
-  std::lock_guard<std::mutex> lock(c->mu);
-  int dev = 0;
-  int ndev = 0;
+}  // extern "C"
+
+namespace {
+// the per-cascade context of the synchronous calls, (re)configured for this geometry and these call parameters
+int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min_neighbors, int min_w, int min_h, int max_w,
+                 int max_h, hc_context** out) {
+  int dev = 0, ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
   HIPCHK(hipGetDevice(&dev));
@@ -1142,10 +1203,163 @@ int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols,
     if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, 1, 1 << 16)))
       return rc;
   }
-  if ((rc = hc_detect_batch_enqueue_host(ctx, gray, 0, step_bytes, 1))) return rc;
+  *out = ctx;
+  return HC_OK;
+}
+
+// H2D copy of one interleaved 8-bit image into the context's colour staging buffer + cvtColor(.., BGR2GRAY) into the
+// gray staging plane (what upstream's detectMultiScale does first with a multi-channel image)
+int stage_color_as_gray(hc_context* ctx, const uint8_t* img, int rows, int cols, int channels, size_t step_bytes) {
+  const size_t rowb = (size_t)cols * channels, need = rowb * rows;
+  if (ctx->color_bytes < need) {
+    if (ctx->d_color) (void)hipFree(ctx->d_color);
+    ctx->d_color = nullptr; ctx->color_bytes = 0;
+    int rc = dev_alloc(&ctx->d_color, need);
+    if (rc) return rc;
+    ctx->color_bytes = need;
+  }
+  if (int rc = ensure_frames(ctx)) return rc;
+  HIPCHK(hipMemcpy2DAsync(ctx->d_color, rowb, img, step_bytes, rowb, rows, hipMemcpyHostToDevice, ctx->stream));
+  int e = hc::launch_bgr2gray(ctx->stream, 1, ctx->d_color, need, rowb, channels, rows, cols, ctx->d_frames, (size_t)rows * cols);
+  if (e) return set_err(HC_ERR_HIP, std::string("k_bgr2gray launch: ") + hipGetErrorString((hipError_t)e));
+  return HC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,
+                         int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h, hc_rect* out,
+                         int out_capacity, int* out_count) {
+  return hc_detect_multiscale_image(c, gray, rows, cols, 1, step_bytes, scale_factor, min_neighbors, flags, min_w, min_h,
+                                    max_w, max_h, out, out_capacity, out_count);
+}
+
+int hc_detect_multiscale_image(hc_cascade* c, const uint8_t* image, int rows, int cols, int channels, size_t step_bytes,
+                               double scale_factor, int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h,
+                               hc_rect* out, int out_capacity, int* out_count) {
+  (void)flags;   // ignored by the OpenCV >= 4 evaluation path for this cascade format (SURVEY A.0)
+  if (!c || !image || !out_count) return set_err(HC_ERR_ARG, "null argument");
+  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
+  if (channels != 1 && channels != 3 && channels != 4) return set_err(HC_ERR_ARG, "8-bit image with 1, 3 or 4 channels required");
+  if (rows <= 0 || cols <= 0 || step_bytes < (size_t)cols * channels) return set_err(HC_ERR_ARG, "bad image geometry");
+  *out_count = 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  hc_context* ctx = nullptr;
+  int rc = sync_context(c, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, &ctx);
+  if (rc) return rc;
+  if (channels == 1) {
+    if ((rc = hc_detect_batch_enqueue_host(ctx, image, 0, step_bytes, 1))) return rc;
+  } else {
+    if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
+    HIPCHK(hipSetDevice(ctx->device));
+    if ((rc = stage_color_as_gray(ctx, image, rows, cols, channels, step_bytes))) return rc;
+    if ((rc = enqueue_device(ctx, ctx->d_frames, (size_t)rows * cols, cols, 1))) return rc;
+  }
   int32_t ofs[2] = {0, 0};
   if ((rc = hc_detect_batch_wait(ctx, out, out_capacity, ofs))) return rc;
   *out_count = ofs[1];
+  return HC_OK;
+}
+
+int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int channels, size_t step_bytes, uint8_t* gray,
+                        size_t gray_step_bytes) {
+  if (!image || !gray) return set_err(HC_ERR_ARG, "null argument");
+  if ((channels != 3 && channels != 4) || rows <= 0 || cols <= 0 || step_bytes < (size_t)cols * channels ||
+      gray_step_bytes < (size_t)cols)
+    return set_err(HC_ERR_ARG, "8-bit image with 3 or 4 channels required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+  const size_t rowb = (size_t)cols * channels;
+  uint8_t *d_src = nullptr, *d_dst = nullptr;
+  int rc = dev_alloc(&d_src, rowb * rows);
+  if (!rc) rc = dev_alloc(&d_dst, (size_t)rows * cols);
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    e = hipMemcpy2D(d_src, rowb, image, step_bytes, rowb, rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = (hipError_t)hc::launch_bgr2gray(nullptr, 1, d_src, rowb * rows, rowb, channels, rows, cols, d_dst, (size_t)rows * cols);
+    if (e == hipSuccess) e = hipMemcpy2D(gray, gray_step_bytes, d_dst, cols, cols, rows, hipMemcpyDeviceToHost);
+  }
+  if (d_src) (void)hipFree(d_src);
+  if (d_dst) (void)hipFree(d_dst);
+  if (rc) return rc;
+  if (e != hipSuccess) return set_err(HC_ERR_HIP, std::string("hc_convert_bgr2gray: ") + hipGetErrorString(e));
+  return HC_OK;
+}
+
+// ---- box files: frame id -> rect list, the hand-over format between a batched / multi-GPU detection
+// run and the sequential tracker.  Layout in include/hip_cascade.h; identical to ugproj-detector_amd/shard.py.
+int hc_boxes_save(const char* path, int nframes, const int32_t* frame_ids, const int32_t* offsets, const hc_rect* rects) {
+  if (!path || nframes < 0 || (nframes > 0 && (!frame_ids || !offsets)) || (nframes > 0 && offsets[nframes] > 0 && !rects))
+    return set_err(HC_ERR_ARG, "hc_boxes_save: null argument");
+  std::vector<int> order(nframes);
+  for (int i = 0; i < nframes; i++) {
+    order[i] = i;
+    if (offsets[i + 1] < offsets[i]) return set_err(HC_ERR_ARG, "hc_boxes_save: offsets must not decrease");
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frame_ids[a] < frame_ids[b]; });   // ascending id
+  for (int i = 1; i < nframes; i++)
+    if (frame_ids[order[i]] == frame_ids[order[i - 1]]) return set_err(HC_ERR_ARG, "hc_boxes_save: duplicate frame id");
+  FILE* f = fopen(path, "wb");
+  if (!f) return set_err(HC_ERR_IO, std::string("cannot create ") + path);
+  const int32_t hdr[2] = {1, nframes};
+  bool ok = fwrite("HCBX", 1, 4, f) == 4 && fwrite(hdr, 4, 2, f) == 2;
+  for (int k = 0; ok && k < nframes; k++) {
+    const int i = order[k];
+    const int32_t rec[2] = {frame_ids[i], offsets[i + 1] - offsets[i]};
+    ok = fwrite(rec, 4, 2, f) == 2;
+    if (ok && rec[1] > 0) ok = fwrite(rects + offsets[i], sizeof(hc_rect), (size_t)rec[1], f) == (size_t)rec[1];
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? HC_OK : set_err(HC_ERR_IO, std::string("short write to ") + path);
+}
+
+int hc_boxes_load(const char* path, int32_t* frame_ids, int32_t* offsets, int frame_capacity, hc_rect* rects, int rect_capacity,
+                  int* nframes, int* nrects) {
+  if (!path || !nframes || !nrects) return set_err(HC_ERR_ARG, "hc_boxes_load: null argument");
+  *nframes = *nrects = 0;
+  FILE* f = fopen(path, "rb");
+  if (!f) return set_err(HC_ERR_IO, std::string("cannot open ") + path);
+  std::string buf;
+  char tmp[1 << 16];
+  size_t n;
+  while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+  fclose(f);
+  if (buf.size() < 12 || memcmp(buf.data(), "HCBX", 4) != 0) return set_err(HC_ERR_FORMAT, "not an HCBX file");
+  int32_t hdr[2];
+  memcpy(hdr, buf.data() + 4, 8);
+  if (hdr[0] != 1 || hdr[1] < 0) return set_err(HC_ERR_FORMAT, "unsupported HCBX version / frame count");
+  // first pass: validate and count, so that a too-small buffer learns the sizes it needs
+  size_t p = 12;
+  long long total = 0;
+  for (int i = 0; i < hdr[1]; i++) {
+    if (p + 8 > buf.size()) return set_err(HC_ERR_FORMAT, "truncated HCBX file");
+    int32_t rec[2];
+    memcpy(rec, buf.data() + p, 8);
+    p += 8;
+    if (rec[1] < 0 || p + (size_t)rec[1] * 16 > buf.size()) return set_err(HC_ERR_FORMAT, "truncated HCBX file");
+    p += (size_t)rec[1] * 16;
+    total += rec[1];
+  }
+  *nframes = hdr[1];
+  *nrects = (int)total;
+  if (!frame_ids && !offsets && !rects) return HC_OK;                       // size query
+  if (hdr[1] > frame_capacity || total > rect_capacity || !frame_ids || !offsets || (total > 0 && !rects))
+    return set_err(HC_ERR_CAPACITY, "hc_boxes_load: output buffers too small (sizes returned)");
+  p = 12;
+  int at = 0;
+  for (int i = 0; i < hdr[1]; i++) {
+    int32_t rec[2];
+    memcpy(rec, buf.data() + p, 8);
+    p += 8;
+    frame_ids[i] = rec[0];
+    offsets[i] = at;
+    if (rec[1] > 0) memcpy(rects + at, buf.data() + p, (size_t)rec[1] * 16);
+    p += (size_t)rec[1] * 16;
+    at += rec[1];
+  }
+  offsets[hdr[1]] = at;
   return HC_OK;
 }
 

@@ -53,6 +53,13 @@ int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t fra
 // INTER_AREA decimation by integer factors (scan-size resize of the tracker)
 int launch_area_decimate(hipStream_t st, int nframes, const uint8_t* src, size_t src_frame_stride, size_t src_row_step,
                          int channels, int fx, int fy, uint8_t* dst, size_t dst_frame_stride, int drows, int dcols);
+// INTER_AREA, any shrinking ratio: per destination column/row the taps [ofs[d], ofs[d+1]) of (si, alpha)
+int launch_area_resize(hipStream_t st, int nframes, const uint8_t* src, size_t src_frame_stride, size_t src_row_step,
+                       int channels, const int* xofs, const int* xsi, const float* xal, const int* yofs, const int* ysi,
+                       const float* yal, uint8_t* dst, size_t dst_frame_stride, int drows, int dcols);
+// cvtColor(BGR2GRAY / BGRA2GRAY): channels = 3 or 4
+int launch_bgr2gray(hipStream_t st, int nframes, const uint8_t* src, size_t frame_stride, size_t row_step, int channels,
+                    int rows, int cols, uint8_t* gray, size_t plane_stride);
 // boxes: nboxes x {frame, x, y, w, h}; sums[i] = sum of mask over box i
 int launch_box_mask_sums(hipStream_t st, const uint32_t* integ, size_t int_stride, int pitch, const int* boxes, int nboxes,
                          uint32_t* sums);

@@ -44,6 +44,26 @@ void build_resize_table(int src, int dst, std::vector<uint32_t>& out) {
   }
 }
 
+void build_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha) {
+  // A destination cell [d*scale, (d+1)*scale) takes a leading partial source cell, whole cells, and a trailing
+  // partial cell, each weighted by the covered length over the cell width; parts thinner than 1e-3 are dropped.
+  const double scale = (double)ssize / (double)dsize;
+  ofs.assign(dsize + 1, 0);
+  si.clear();
+  alpha.clear();
+  for (int d = 0; d < dsize; d++) {
+    ofs[d] = (int)si.size();
+    const double begin = d * scale, end = begin + scale;
+    const double width = std::min(scale, ssize - begin);
+    int whole_end = std::min((int)std::floor(end), ssize - 1);
+    int whole_begin = std::min((int)std::ceil(begin), whole_end);
+    if (whole_begin - begin > 1e-3) { si.push_back(whole_begin - 1); alpha.push_back((float)((whole_begin - begin) / width)); }
+    for (int s = whole_begin; s < whole_end; s++) { si.push_back(s); alpha.push_back((float)(1.0 / width)); }
+    if (end - whole_end > 1e-3) { si.push_back(whole_end); alpha.push_back((float)(std::min(std::min(end - whole_end, 1.), width) / width)); }
+  }
+  ofs[dsize] = (int)si.size();
+}
+
 int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
                int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p) {
   p = Plan{};

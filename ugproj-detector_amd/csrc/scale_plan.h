@@ -40,4 +40,8 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
 // (ofs << 9) | c1 for every destination index of a src -> dst exact bilinear resize
 void build_resize_table(int src, int dst, std::vector<uint32_t>& out);
 
+// cv::resize(INTER_AREA) tap table of one axis for a shrinking, non-integer ratio (computeResizeAreaTab):
+// destination index d covers taps [ofs[d], ofs[d+1]) of (si[k], alpha[k]); f64 arithmetic, alpha rounded to f32.
+void build_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<int>& si, std::vector<float>& alpha);
+
 }  // namespace hc

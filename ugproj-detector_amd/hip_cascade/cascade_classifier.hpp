@@ -15,7 +15,7 @@
 // repository's build and tests) layout-compatible PODs stand in.
 //
 // Error behaviour mirrors OpenCV: load() returns false on failure; detectMultiScale() throws
-// on scaleFactor <= 1 or a non-8-bit single-channel image (cv::Exception upstream, which the
+// on scaleFactor <= 1 or a non-8-bit image (cv::Exception upstream, which the
 // reference never catches: src/tracker/main.cc:14-41) and on any device failure -- there is
 // no CPU fallback to hide behind.
 #pragma once
@@ -43,6 +43,7 @@ inline int mat_cols(const Mat& m) { return m.cols; }
 inline size_t mat_step(const Mat& m) { return m.step; }
 inline bool mat_is_u8c1(const Mat& m) { return m.type() == CV_8UC1; }
 inline bool mat_is_u8c3(const Mat& m) { return m.type() == CV_8UC3; }
+inline int mat_u8_channels(const Mat& m) { return m.depth() == CV_8U ? m.channels() : 0; }
 using Scalar = cv::Scalar;
 #else
 struct Rect { int x = 0, y = 0, width = 0, height = 0; };
@@ -72,6 +73,7 @@ inline int mat_cols(const Mat& m) { return m.cols; }
 inline size_t mat_step(const Mat& m) { return m.step; }
 inline bool mat_is_u8c1(const Mat& m) { return m.nchannels == 1; }
 inline bool mat_is_u8c3(const Mat& m) { return m.nchannels == 3; }
+inline int mat_u8_channels(const Mat& m) { return m.nchannels; }
 #endif
 static_assert(sizeof(Rect) == sizeof(hc_rect), "Rect must be layout-compatible with hc_rect");
 
@@ -96,16 +98,19 @@ class CascadeClassifier {
                         int flags = 0, Size minSize = Size(), Size maxSize = Size()) {
     objects.clear();                                    // upstream clears the output first
     if (empty()) return;                                // upstream: empty classifier -> no detections
-    if (!(scaleFactor > 1.0) || !mat_is_u8c1(image) || !mat_data(image))
-      throw std::invalid_argument("hip_cascade::detectMultiScale: scaleFactor > 1 and an 8-bit 1-channel image required");
+    // upstream: CV_Assert(scaleFactor > 1 && image.depth() == CV_8U); a colour image is converted with
+    // cvtColor(image, gray, COLOR_BGR2GRAY) first -- the backend does the same on device
+    const int ch = mat_u8_channels(image);
+    if (!(scaleFactor > 1.0) || (ch != 1 && ch != 3 && ch != 4) || !mat_data(image))
+      throw std::invalid_argument("hip_cascade::detectMultiScale: scaleFactor > 1 and an 8-bit image with 1, 3 or 4 channels required");
     int cap = 1024;
     for (;;) {
       objects.resize(cap);
       int n = 0;
-      const int rc = hc_detect_multiscale(h_, mat_data(image), mat_rows(image), mat_cols(image), mat_step(image),
-                                          scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
-                                          maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
-                                          cap, &n);
+      const int rc = hc_detect_multiscale_image(h_, mat_data(image), mat_rows(image), mat_cols(image), ch, mat_step(image),
+                                                scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
+                                                maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
+                                                cap, &n);
       if (rc == HC_ERR_CAPACITY && cap < (1 << 22)) { cap *= 4; continue; }
       if (rc != HC_OK) {
         objects.clear();
