@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -13,6 +15,7 @@
 #include "../../ugproj-detector_amd/csrc/group_rects.h"
 #include "../../ugproj-detector_amd/csrc/scale_plan.h"
 #include "../../oracle/haar_oracle.h"
+#include "../../ugproj-detector_amd/hip_cascade/box_records.hpp"
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint32_t rnd() {
@@ -105,6 +108,48 @@ int main(int argc, char** argv) {
       r.push_back(hc_rect{(int)(rnd() % 300), (int)(rnd() % 200), s, s});
     }
     hc::group_rectangles(r, (int)(rnd() % 4), 0.2);
+  }
+  // box records of the multi-GPU gather (hip_cascade/box_records.hpp): 3 "ranks" x 5 records, frames with 0, a few,
+  // exactly 64 and far more than 64 boxes, padding records, ranks that overflow by different amounts
+  {
+    const int world = 3, per = 5;
+    std::vector<int32_t> gathered;
+    std::vector<std::vector<hc_rect>> blocks(world);
+    std::map<int32_t, std::vector<hc_rect>> want;
+    size_t stride = 0;
+    for (int r = 0; r < world; r++) {
+      std::vector<int32_t> ids(per), ofs(per + 1, 0), rec;
+      std::vector<hc_rect> rects;
+      for (int i = 0; i < per; i++) {
+        const int fid = r * per + i;
+        ids[i] = (r == 2 && i == per - 1) ? -1 : fid;                       // one padding record
+        const int n = ids[i] < 0 ? 0 : (fid % 4 == 0 ? 64 + 9 * fid : (fid % 4 == 1 ? 64 : fid % 7));
+        for (int k = 0; k < n; k++) rects.push_back(hc_rect{fid, k, 30 + k % 5, 30 + k % 5});
+        ofs[i + 1] = (int32_t)rects.size();
+        if (ids[i] >= 0) want[fid] = std::vector<hc_rect>(rects.begin() + ofs[i], rects.end());
+      }
+      hip_cascade::pack_records(ids.data(), per, ofs.data(), rects.data(), rec, blocks[r]);
+      gathered.insert(gathered.end(), rec.begin(), rec.end());
+      stride = std::max(stride, blocks[r].size());
+    }
+    const std::vector<int64_t> over = hip_cascade::overflow_counts(gathered.data(), world, per);
+    std::vector<hc_rect> ov((size_t)world * stride, hc_rect{-7, -7, -7, -7});
+    for (int r = 0; r < world; r++) {
+      if ((size_t)over[r] != blocks[r].size()) return 20;
+      std::copy(blocks[r].begin(), blocks[r].end(), ov.begin() + (size_t)r * stride);
+    }
+    if (stride == 0) return 21;
+    auto got = hip_cascade::unpack_records(gathered.data(), world, per, ov.data(), stride);
+    if (got.size() != want.size()) return 22;
+    for (auto& kv : want) {
+      const auto& g = got[kv.first];
+      if (g.size() != kv.second.size()) return 23;
+      for (size_t k = 0; k < g.size(); k++)
+        if (g[k].x != kv.second[k].x || g[k].y != kv.second[k].y || g[k].width != kv.second[k].width) return 24;
+    }
+    bool threw = false;
+    try { hip_cascade::unpack_records(gathered.data(), world, per, ov.data(), stride - 1); } catch (const std::runtime_error&) { threw = true; }
+    if (!threw) return 25;                                                  // a short block is an error, never a silent loss
   }
   std::vector<uint32_t> t;
   for (int dst = 1; dst < 400; dst += 7) hc::build_resize_table(1 + rnd() % 2000, dst, t);

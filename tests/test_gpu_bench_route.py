@@ -179,3 +179,31 @@ def test_bench_rccl_gather_single_rank(pkg):
     out = _run_bench(["--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "20", "--cpu-sample", "0"])
     assert out["parity"]["bit_exact"] is True and out["parity"]["gathered_frames"] == 20
     assert "RCCL" in out["config"]["parallelism"] and "roofline" in out
+
+
+@pytest.mark.parametrize("min_neighbors", [2, 0])
+def test_cpp_multi_gpu_demo_single_device(pkg, oracle, synth, tmp_path, min_neighbors):
+    """SURVEY section 7 step 10 from plain C++ (hip_cascade/multi_gpu_demo.cpp): one process, ncclCommInitAll, a feeder
+    thread and a context pair per GPU, grouped ncclAllGather of box records (+ the overflow round with minNeighbors 0,
+    where frames carry hundreds of rectangles), HCBX file written through hc_boxes_save.  One device is what this box
+    has; the gathered, frame-ordered box file must equal the oracle frame by frame, ragged last batch included."""
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "multi_gpu_demo")
+    n = 11                                                   # batch 4: two full global batches + a ragged one
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(70 + i), nfaces=3, min_size=40, max_size=110)[0] for i in range(n)])
+    f = tmp_path / "frames.u8"
+    frames.tofile(f)
+    out = tmp_path / "boxes.hcbx"
+    r = subprocess.run([demo, oracle.cascade_path("alt"), str(f), str(n), "240", "320", "1", "4", "2", str(out), str(min_neighbors)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = pkg.load_boxes(str(out))
+    assert sorted(got) == list(range(n))
+    oc = oracle.OracleCascade(oracle.cascade_path("alt"))
+    total = 0
+    for i in range(n):
+        want, _ = oc.detect(frames[i], 1.1, min_neighbors, (30, 30))
+        assert np.array_equal(got[i], want), i
+        total += len(want)
+    assert ("%d boxes per pass" % total) in r.stdout, r.stdout
+    if min_neighbors == 0:
+        assert max(len(b) for b in got.values()) > 64
