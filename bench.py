@@ -202,12 +202,15 @@ def rank_main(args):
         stream = None   # each context owns a stream: kernels of batch i+1 may overlap the tail of batch i
     slots = []
     for _ in range(2):
-        cs = []
-        for casc in cascs:
-            c = pkg.Context(casc, device=devno, stream=stream)
-            c.configure(rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
-                        max_batch=B, cand_capacity=4096)
-            cs.append(c)
+        cs = [pkg.Context(casc, device=devno, stream=stream) for casc in cascs]
+        if len(cs) == 1:
+            cs[0].configure(rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
+                            max_batch=B, cand_capacity=4096)
+        else:
+            # several cascades over the same frames: ONE pyramid + integral pass over the union of their scale ladders
+            # (cs[0] leads), then each cascade's own variance + cascade kernels
+            pkg.configure_shared(cs, rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
+                                 max_batch=B, cand_capacity=4096)
         slots.append(cs)
     alg_bytes = sum(c.algorithmic_bytes() for c in slots[0])      # multi-cascade configs sum the per-cascade figures
 
@@ -321,7 +324,8 @@ def rank_main(args):
             "config": {"workload": "%s, scaleFactor 1.1, minNeighbors 2, minSize 30x30, S3 '%s' frames"
                                    % (cfg["label"] if not args.cascade else "%dx%d gray, %s" % (cols, rows, cnames), args.kind),
                        "frames_per_gpu_per_step": B, "distinct_frames_per_gpu": ndist,
-                       "levels": [len(c.levels()) for c in slots[0]],
+                       "levels": [sum(1 for L in c.levels() if L.nx > 0) for c in slots[0]],
+                       "shared_prep_levels": len(slots[0][0].levels()) if len(slots[0]) > 1 else None,
                        "parallelism": "frame-shard x%d, %s all-gather of box records"
                                       % (world, "RCCL" if args.backend == "nccl" else "gloo")},
             "parity": parity,

@@ -106,6 +106,21 @@ HC_API void hc_context_destroy(hc_context* ctx);
 HC_API int  hc_context_configure(hc_context* ctx, int rows, int cols, double scale_factor,
                                  int min_neighbors, int min_w, int min_h, int max_w, int max_h,
                                  int max_batch, int cand_capacity);
+/* Several cascades over the SAME frames in one pass (BASELINE.json configs #3: alt2 + default, #5: all four):
+ * ctxs[0..n) are contexts of different cascades on one device.  Pyramid level geometry depends on the scale
+ * alone, so one pyramid + integral pass over the union of the cascades' scale ladders serves them all: ctxs[0]
+ * (the leader) owns those integrals, the other contexts (followers) only run their own variance and cascade
+ * kernels on them.  Per batch: enqueue the leader first, then each follower once with the same batch (a
+ * follower takes the frames from the leader's pass; its frame pointer argument is ignored), then wait on each
+ * context for its cascade's rectangles.  Cross-stream ordering (followers behind the leader's prep kernels, the
+ * leader's next batch behind the followers' scans) is handled with events, so the contexts may own their
+ * streams or share one.  Reconfiguring or destroying the leader leaves the followers unconfigured.
+ * hc_context_algorithmic_bytes stays each cascade's own full figure (sharing is an optimisation, not a
+ * discount); hc_context_levels of any member lists the union ladder, levels outside that cascade's own ladder
+ * with an empty grid (nx = ny = 0). */
+HC_API int  hc_context_configure_shared(hc_context* const* ctxs, int n, int rows, int cols, double scale_factor,
+                                        int min_neighbors, int min_w, int min_h, int max_w, int max_h,
+                                        int max_batch, int cand_capacity);
 /* Enqueue detection of nframes 8-bit gray frames that already live in device memory
  * (frame f at d_frames + f*frame_stride_bytes, rows row_step_bytes apart). Asynchronous. */
 HC_API int  hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes,

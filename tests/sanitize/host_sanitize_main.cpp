@@ -2,6 +2,7 @@
 // product's pure-host code -- cascade loader (HCC1 + XML when reachable), scale planning, resize
 // tables, rectangle grouping -- and the CPU oracle end to end, under -fsanitize=address,undefined.
 // Built and run by tests/test_sanitize.py.  Exit code 0 and no sanitizer report = pass.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -59,6 +60,41 @@ int main(int argc, char** argv) {
     const int lo[3] = {0, 133, 77}, hi[3] = {255, 173, 127};
     if (orc_detect_faces(oc, bgr.data(), 120, 160, 480, lo, hi, 1.1, out.data(), 1024, &n, nullptr, nullptr)) return 6;
     orc_cascade_free(oc);
+  }
+  // shared prep pass (hc_context_configure_shared): a plan laid out over the union of two cascades' ladders scans
+  // exactly the levels, grids and stripes of the cascade's own plan; the other levels have empty grids
+  if (argc >= 4) {
+    hc::Model a, b;
+    std::string err;
+    if (hc::load_model(argv[2], a, err) || hc::load_model(argv[3], b, err)) return 30;      // alt2 (win 20), default (win 24)
+    const int geo[][2] = {{1080, 1920}, {720, 1280}, {97, 131}, {23, 40}};
+    for (const auto& g : geo) {
+      std::vector<float> la = hc::scale_ladder(a, g[0], g[1], 1.1, 30, 30, 0, 0), lb = hc::scale_ladder(b, g[0], g[1], 1.1, 30, 30, 0, 0);
+      std::vector<float> uni = la;
+      for (float s : lb) if (std::find(uni.begin(), uni.end(), s) == uni.end()) uni.push_back(s);
+      std::sort(uni.begin(), uni.end());
+      const hc::Model* ms[2] = {&a, &b};
+      for (int k = 0; k < 2; k++) {
+        hc::Plan own, sh;
+        if (hc::build_plan(*ms[k], g[0], g[1], 1.1, 30, 30, 0, 0, 16, 16, own)) return 31;
+        if (hc::build_plan(*ms[k], g[0], g[1], 1.1, 30, 30, 0, 0, 16, 16, sh, &uni)) return 32;
+        if (sh.levels.size() != uni.size() || sh.algorithmic_bytes != own.algorithmic_bytes || sh.nstripes != own.nstripes) return 33;
+        size_t j = 0, bands_own = own.band_items[0].size() + own.band_items[1].size();
+        for (size_t i = 0; i < sh.levels.size(); i++) {
+          const hc::DevLevel& L = sh.levels[i];
+          if (!sh.scanned[i]) { if (L.nx || L.ny || L.ny_all) return 34; continue; }
+          const hc::DevLevel& O = own.levels[j++];
+          if (L.scale != O.scale || L.w != O.w || L.h != O.h || L.nx != O.nx || L.ny != O.ny || L.y_end != O.y_end ||
+              L.win_w != O.win_w || L.ystep != O.ystep || L.int_pitch != O.int_pitch)
+            return 35;
+        }
+        if (j != own.levels.size() || sh.band_items[0].size() + sh.band_items[1].size() != bands_own) return 36;
+      }
+      if (g[0] == 1080 && (uni.size() != 39 || la.size() != 37 || lb.size() != 37)) return 37;   // k = 3..41: 5..41 and 3..39
+    }
+    std::vector<float> bad = {1.5f};
+    hc::Plan p;
+    if (hc::build_plan(a, 720, 1280, 1.1, 30, 30, 0, 0, 16, 16, p, &bad) == 0) return 38;       // not a superset: refused
   }
   // malformed HCC1 containers must be rejected by the loader (never indexed out of bounds later):
   // truncations at every 997th byte, a stage with zero / negative / oversized tree counts, a window <= 2

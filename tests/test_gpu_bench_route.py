@@ -207,3 +207,58 @@ def test_cpp_multi_gpu_demo_single_device(pkg, oracle, synth, tmp_path, min_neig
     assert ("%d boxes per pass" % total) in r.stdout, r.stdout
     if min_neighbors == 0:
         assert max(len(b) for b in got.values()) > 64
+
+
+def _scanned_level_taps(ctx, pkg, frame_index):
+    """stage taps of the levels a member of a shared group scans itself, in ladder order"""
+    return [ctx.read_tap(frame_index, li, pkg.TAP_STAGES) for li, L in enumerate(ctx.levels()) if L.nx > 0]
+
+
+@pytest.mark.parametrize("names,shape", [(("alt2", "default"), (360, 640)), (("default", "alt", "alt_tree", "alt2"), (240, 320)),
+                                         (("alt2", "default"), (1080, 1920))])
+def test_shared_prep_pass_equals_separate_contexts(pkg, oracle, synth, names, shape):
+    """BASELINE configs #3 / #5 as ONE pass: contexts of several cascades configured with hc_context_configure_shared
+    take their integrals from one pyramid + integral pass over the union ladder (win 20 and win 24 ladders differ at
+    both ends).  Each member's stage taps, raw candidates and boxes equal the oracle's for its cascade -- two
+    consecutive batches, leader first then the followers, every member on its own stream."""
+    rows, cols = shape
+    nf = 3 if rows < 1000 else 2
+    batches = [np.stack([synth.planted(rows, cols, synth.frame_seed(80 + 10 * b + i), nfaces=4, min_size=40,
+                                       max_size=min(rows, cols) // 2)[0] for i in range(nf)]) for b in range(2)]
+    cascs = [pkg.Cascade(oracle.cascade_path(n)) for n in names]
+    ocs = [oracle.OracleCascade(oracle.cascade_path(n)) for n in names]
+    ctxs = [pkg.Context(c) for c in cascs]
+    pkg.configure_shared(ctxs, rows, cols, 1.1, 2, (30, 30), (0, 0), max_batch=nf, cand_capacity=1 << 14)
+    nlev = len(ctxs[0].levels())
+    assert all(len(c.levels()) == nlev for c in ctxs)
+    own = [len(oc.plan(rows, cols, 1.1, (30, 30))[0]) for oc in ocs]
+    assert nlev >= max(own) and [sum(1 for L in c.levels() if L.nx > 0) for c in ctxs] == own
+    if set(names) == {"alt2", "default"} and rows == 1080:
+        assert nlev == 39 and own == [37, 37]
+        assert [c.algorithmic_bytes() for c in ctxs] == [76051696, 110293312]        # each cascade's own full figure
+    for c in ctxs:
+        c.enable_stage_taps(True)
+    with pytest.raises(pkg.HipCascadeError):
+        ctxs[1].enqueue_host(batches[0])                      # a follower cannot run ahead of its leader
+    for frames in batches:
+        for c in ctxs:                                        # leader first, then every follower once
+            c.enqueue_host(frames)
+        for c, oc, name in zip(ctxs, ocs, names):
+            got = c.wait(nf)
+            raws = c.raw_candidates(nf)
+            for f in range(nf):
+                grouped, raw, otaps = oc.detect(frames[f], 1.1, 2, (30, 30), (0, 0), want_taps=True)
+                taps = _scanned_level_taps(c, pkg, f)
+                assert len(taps) == len(otaps)
+                for li, (a, b) in enumerate(zip(taps, otaps)):
+                    assert np.array_equal(a, b), (name, f, li)
+                assert np.array_equal(raws[f], raw), (name, f)
+                assert np.array_equal(got[f], grouped), (name, f)
+    # the leader alone (followers skipped for a batch) still works, and a reconfigured leader detaches its followers
+    ctxs[0].enqueue_host(batches[0])
+    first = ctxs[0].wait(nf)
+    want0 = [ocs[0].detect(fr, 1.1, 2, (30, 30))[0] for fr in batches[0]]
+    assert all(np.array_equal(a, b) for a, b in zip(first, want0))
+    ctxs[0].configure(rows, cols, 1.1, 2, (30, 30), (0, 0), max_batch=nf)
+    with pytest.raises(pkg.HipCascadeError):
+        ctxs[1].enqueue_host(batches[0])

@@ -75,6 +75,7 @@ _SIGS = {
     "hc_context_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hc_context_destroy": (None, [C.c_void_p]),
     "hc_context_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
+    "hc_context_configure_shared": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
     "hc_detect_batch_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]),
     "hc_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "hc_host_free": (None, [C.c_void_p]),
@@ -315,6 +316,17 @@ class Context:
         if a.size:
             _check(lib.hc_context_read_tap(self._h, frame, level_index, what, a.ctypes.data, a.nbytes))
         return a
+
+
+def configure_shared(contexts, rows, cols, scale_factor=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), max_batch=1,
+                     cand_capacity=0):
+    """hc_context_configure_shared: contexts of different cascades over the same frames, one pyramid + integral pass
+    (contexts[0] leads: enqueue it first, then every follower once, per batch)."""
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    _check(lib.hc_context_configure_shared(arr, len(contexts), rows, cols, scale_factor, min_neighbors, min_size[0],
+                                           min_size[1], max_size[0], max_size[1], max_batch, cand_capacity))
+    for c in contexts:
+        c.rows, c.cols, c.max_batch = rows, cols, max_batch
 
 
 def bgr2gray(img):

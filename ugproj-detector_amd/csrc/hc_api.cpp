@@ -135,6 +135,14 @@ struct hc_context {
 
   hc::Plan plan;
   bool configured = false;
+  // several cascades over the same frames (hc_context_configure_shared): the leader owns the pyramid integrals of
+  // the union ladder, followers read them.  prep_seq counts the leader's enqueues; a follower scans each once.
+  hc_context* leader = nullptr;
+  std::vector<hc_context*> followers;
+  unsigned long long prep_seq = 0, seen_seq = 0;
+  int prep_frames = 0;
+  hipEvent_t ev_prep = nullptr;        // leader: recorded after the prep kernels of a batch
+  bool scan_in_flight = false;         // follower: ev_done of its last scan has been recorded and not yet waited by the leader
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
   size_t cand_cap = 0;                   // raw-candidate capacity of d_cand / h_cand for a whole batch (grows on demand)
   // cascade-kernel tiling per ystep class (index 0: ystep 1, index 1: ystep 2)
@@ -216,6 +224,18 @@ struct hc_context {
   int host_threads = 4;   // 1 thread already hides the 64-frame grouping under the next batch (tools/exp_host_threads.sh)
 
   void free_workspace() {
+    if (leader) {                      // follower: the integrals belong to the leader
+      d_sum = d_sq = nullptr;
+      auto& f = leader->followers;
+      f.erase(std::remove(f.begin(), f.end(), this), f.end());
+      leader = nullptr;
+    }
+    for (hc_context* f : followers) {  // leader going away: followers lose their integrals and must be reconfigured
+      f->d_sum = f->d_sq = nullptr;
+      f->leader = nullptr;
+      f->configured = false;
+    }
+    followers.clear();
     void* ptrs[] = {d_frames, d_color, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
                     d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_seg_items[0], d_seg_items[1], d_cand,
                     d_count, d_area_xofs, d_area_xsi, d_area_xal, d_area_yofs, d_area_ysi, d_area_yal};
@@ -405,6 +425,20 @@ hc_level to_public(const hc::DevLevel& L) {
   return o;
 }
 
+// A group that shares one prep pass is enqueued leader first, then every follower once, with the same batch.
+int shared_enqueue_check(hc_context* c, int nframes) {
+  if (c->leader) {
+    hc_context* L = c->leader;
+    if (L->prep_seq == c->seen_seq) return set_err(HC_ERR_STATE, "shared prep: enqueue the leader's batch first (once per follower scan)");
+    if (L->prep_frames != nframes) return set_err(HC_ERR_ARG, "shared prep: follower batch size differs from the leader's");
+    c->seen_seq = L->prep_seq;
+  } else if (!c->followers.empty()) {
+    c->prep_seq++;
+    c->prep_frames = nframes;
+  }
+  return HC_OK;
+}
+
 // first-use allocations (outside the steady state: a context that has run one batch of a kind never allocates again)
 int ensure_frames(hc_context* c) {
   if (c->d_frames) return HC_OK;
@@ -424,11 +458,13 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   const hc::Model& m = c->casc->model;
   hipStream_t s = c->stream;
   c->inflight_src = d_frames; c->inflight_frame_stride = frame_stride; c->inflight_row_step = row_step;
+  for (hc_context* f : c->followers)   // the next prep pass overwrites the integrals: the followers' scans of the last one come first
+    if (f->scan_in_flight) { HIPCHK(hipStreamWaitEvent(s, f->ev_done, 0)); f->scan_in_flight = false; }
   {
     const double equiv0 = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
     const bool fused0 = c->fused_prep > 0 || (c->fused_prep < 0 && equiv0 > c->fused_min_batch);
     int rc0;
-    if (!P.levels.empty() && (c->taps_enabled || !fused0) && (rc0 = ensure_pyr(c))) return rc0;
+    if (!c->leader && !P.levels.empty() && (c->taps_enabled || !fused0) && (rc0 = ensure_pyr(c))) return rc0;
     if (!P.levels.empty() && c->taps_enabled && (rc0 = ensure_taps(c))) return rc0;
   }
   HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), s));
@@ -441,7 +477,11 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
     // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
     const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
-    if (c->fused_prep > 0 || (c->fused_prep < 0 && equiv > c->fused_min_batch)) {
+    if (c->leader) {
+      // shared prep: the leader's kernels have produced (or are producing) the integrals of this very batch
+      HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
+      if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
+    } else if (c->fused_prep > 0 || (c->fused_prep < 0 && equiv > c->fused_min_batch)) {
       int max_w = 0;
       for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
       // the pyramid bytes only exist as a debug tap in this mode
@@ -463,6 +503,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                         c->d_sq, int_stride)))
         return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
     }
+    if (!c->followers.empty()) HIPCHK(hipEventRecord(c->ev_prep, s));
     if (timed) HIPCHK(hipEventRecord(c->ev[3], s));
     if ((e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
@@ -504,6 +545,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   // results travel on the side stream, ordered after this batch only (not after whatever the
   // caller enqueues next on `stream`, e.g. the next batch of a software pipeline)
   HIPCHK(hipEventRecord(c->ev_done, s));
+  if (c->leader) c->scan_in_flight = true;
   HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done, 0));
   HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->copy_stream));
   c->pending = nframes;
@@ -601,6 +643,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
       hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
     hc_context_destroy(ctx);
     return set_err(HC_ERR_HIP, "cannot create the result stream / event");
@@ -636,6 +679,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   ctx->free_workspace();
@@ -646,8 +690,13 @@ void hc_context_destroy(hc_context* ctx) {
   delete ctx;
 }
 
-int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_factor, int min_neighbors, int min_w,
-                         int min_h, int max_w, int max_h, int max_batch, int cand_capacity) {
+}  // extern "C"
+
+namespace {
+// prep_scales / leader: null for a context on its own; for a group sharing one prep pass, the union ladder and (for
+// followers) the context whose workspace holds the integrals
+int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int min_neighbors, int min_w, int min_h, int max_w,
+                   int max_h, int max_batch, int cand_capacity, const std::vector<float>* prep_scales, hc_context* leader) {
   if (!ctx) return set_err(HC_ERR_ARG, "null context");
   if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");   // CV_Assert upstream
   if (rows <= 0 || cols <= 0 || max_batch <= 0 || max_batch > 65535) return set_err(HC_ERR_ARG, "bad geometry / batch");
@@ -656,7 +705,7 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   ctx->free_workspace();
   hc::Plan& P = ctx->plan;
   int rc = hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_rows[0],
-                          ctx->band_rows[1], P);
+                          ctx->band_rows[1], P, prep_scales);
   if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
   for (const hc::DevLevel& L : P.levels)
     if (L.nx > 65535 || L.ny_all > 65535 || P.levels.size() > 255) return set_err(HC_ERR_UNSUPPORTED, "frame too large");
@@ -664,15 +713,26 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   ctx->min_neighbors = min_neighbors;
   ctx->cand_per_frame = cand_capacity > 0 ? cand_capacity : 4096;
   const size_t B = (size_t)max_batch;
-  if ((rc = dev_alloc(&ctx->d_sum, B * P.int_words))) return rc;
-  if ((rc = dev_alloc(&ctx->d_sq, B * P.int_words))) return rc;
+  if (leader) {
+    if (leader->plan.int_words != P.int_words || leader->max_batch != max_batch || leader->device != ctx->device)
+      return set_err(HC_ERR_STATE, "shared prep: integral layouts of leader and follower differ");
+    ctx->d_sum = leader->d_sum;
+    ctx->d_sq = leader->d_sq;
+    ctx->leader = leader;
+    leader->followers.push_back(ctx);
+    ctx->seen_seq = leader->prep_seq;
+    ctx->scan_in_flight = false;
+  } else {
+    if ((rc = dev_alloc(&ctx->d_sum, B * P.int_words))) return rc;
+    if ((rc = dev_alloc(&ctx->d_sq, B * P.int_words))) return rc;
+    // row 0 / column 0 of every integral stay zero for the lifetime of the workspace
+    HIPCHK(hipMemset(ctx->d_sum, 0, std::max<size_t>(B * P.int_words, 1) * 4));
+    HIPCHK(hipMemset(ctx->d_sq, 0, std::max<size_t>(B * P.int_words, 1) * 4));
+  }
   if ((rc = dev_alloc(&ctx->d_vnf, B * P.grid_elems))) return rc;
   ctx->cand_cap = B * ctx->cand_per_frame;
   if ((rc = dev_alloc(&ctx->d_cand, ctx->cand_cap))) return rc;
   if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
-  // row 0 / column 0 of every integral stay zero for the lifetime of the workspace
-  HIPCHK(hipMemset(ctx->d_sum, 0, std::max<size_t>(B * P.int_words, 1) * 4));
-  HIPCHK(hipMemset(ctx->d_sq, 0, std::max<size_t>(B * P.int_words, 1) * 4));
   HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
   if ((rc = dev_upload(&ctx->d_levels, P.levels))) return rc;
   if ((rc = dev_upload(&ctx->d_xtab, P.xtab))) return rc;
@@ -700,6 +760,38 @@ int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_facto
   ctx->configured = true;
   return HC_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int hc_context_configure(hc_context* ctx, int rows, int cols, double scale_factor, int min_neighbors, int min_w,
+                         int min_h, int max_w, int max_h, int max_batch, int cand_capacity) {
+  return configure_impl(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, max_batch, cand_capacity,
+                        nullptr, nullptr);
+}
+
+int hc_context_configure_shared(hc_context* const* ctxs, int n, int rows, int cols, double scale_factor, int min_neighbors,
+                                int min_w, int min_h, int max_w, int max_h, int max_batch, int cand_capacity) {
+  if (!ctxs || n < 1) return set_err(HC_ERR_ARG, "hc_context_configure_shared: no contexts");
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return set_err(HC_ERR_ARG, "null context");
+    if (ctxs[i]->device != ctxs[0]->device) return set_err(HC_ERR_ARG, "shared prep: contexts must live on one device");
+    for (int j = 0; j < i; j++)
+      if (ctxs[i] == ctxs[j]) return set_err(HC_ERR_ARG, "shared prep: the same context twice");
+  }
+  // union of the ladders: one pyramid + integral pass serves every cascade (levels depend on the scale only)
+  std::vector<float> prep;
+  for (int i = 0; i < n; i++)
+    for (float sc : hc::scale_ladder(ctxs[i]->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h))
+      if (std::find(prep.begin(), prep.end(), sc) == prep.end()) prep.push_back(sc);
+  std::sort(prep.begin(), prep.end());
+  int rc = configure_impl(ctxs[0], rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, max_batch, cand_capacity,
+                          &prep, nullptr);
+  for (int i = 1; i < n && rc == HC_OK; i++)
+    rc = configure_impl(ctxs[i], rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, max_batch, cand_capacity,
+                        &prep, ctxs[0]);
+  return rc;
+}
 
 int hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes, size_t row_step_bytes,
                             int nframes) {
@@ -708,6 +800,7 @@ int hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t fra
   if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
+  if (int rc = shared_enqueue_check(ctx, nframes)) return rc;
   return enqueue_device(ctx, d_frames, frame_stride_bytes, row_step_bytes, nframes);
 }
 
@@ -718,6 +811,8 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
+  if (int rc = shared_enqueue_check(ctx, nframes)) return rc;
+  if (ctx->leader) return enqueue_device(ctx, h_frames, frame_stride_bytes, row_step_bytes, nframes);   // frames went up with the leader
   if (int rc = ensure_frames(ctx)) return rc;
   const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
   if (row_step_bytes == cols && (nframes == 1 || frame_stride_bytes == rows * cols)) {
@@ -769,8 +864,9 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
     if (count <= ctx->cand_cap) break;
     // More raw candidates than the workspace holds (the counter keeps counting past the capacity, so the need is
     // known exactly).  OpenCV would simply return more rectangles: grow the buffers and run the batch again.
-    if (attempt >= 2 || !ctx->inflight_src)
-      return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow and the batch cannot be re-run");
+    if (attempt >= 2 || !ctx->inflight_src || (ctx->leader && ctx->leader->prep_seq != ctx->seen_seq))
+      return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow and the batch cannot be re-run "
+                                           "(shared prep: the leader has already moved on); raise cand_capacity");
     const size_t want = (size_t)count + (size_t)count / 4 + 1024;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_cand); ctx->d_cand = nullptr;

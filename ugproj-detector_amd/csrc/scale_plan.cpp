@@ -64,20 +64,12 @@ void build_area_table(int ssize, int dsize, std::vector<int>& ofs, std::vector<i
   ofs[dsize] = (int)si.size();
 }
 
-int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
-               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p) {
-  p = Plan{};
-  p.band_rows[0] = band_rows_ystep1;
-  p.band_rows[1] = band_rows_ystep2;
-  p.rows = rows; p.cols = cols; p.scale_factor = scale_factor;
-  p.min_w = min_w; p.min_h = min_h;
-  if (!(scale_factor > 1.0) || rows <= 0 || cols <= 0) return HC_ERR_ARG;
+std::vector<float> scale_ladder(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w,
+                                int max_h) {
+  std::vector<float> ladder;
+  if (!(scale_factor > 1.0) || rows < m.win_h || cols < m.win_w) return ladder;
   if (max_w == 0 || max_h == 0) { max_w = cols; max_h = rows; }
-  p.max_w = max_w; p.max_h = max_h;
-  p.algorithmic_bytes = (int64_t)rows * cols;
-  if (rows < m.win_h || cols < m.win_w) return HC_OK;
-
-  // ---- scale ladder: every factor whose window fits the image, then the min/max filter
+  // every factor whose window fits the image, then the min/max filter
   std::vector<float> fits;
   {
     double factor = 1.0;
@@ -86,7 +78,6 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
       factor *= scale_factor;
     }
   }
-  std::vector<float> ladder;
   for (float s : fits) {
     const int ww = rne((float)m.win_w * s), wh = rne((float)m.win_h * s);
     if (ww > max_w || wh > max_h) break;
@@ -103,17 +94,42 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
     }
     ladder.push_back(fits[best]);
   }
-  if (ladder.empty()) return HC_OK;
+  return ladder;
+}
+
+int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
+               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p,
+               const std::vector<float>* prep_scales) {
+  p = Plan{};
+  p.band_rows[0] = band_rows_ystep1;
+  p.band_rows[1] = band_rows_ystep2;
+  p.rows = rows; p.cols = cols; p.scale_factor = scale_factor;
+  p.min_w = min_w; p.min_h = min_h;
+  if (!(scale_factor > 1.0) || rows <= 0 || cols <= 0) return HC_ERR_ARG;
+  if (max_w == 0 || max_h == 0) { max_w = cols; max_h = rows; }
+  p.max_w = max_w; p.max_h = max_h;
+  p.algorithmic_bytes = (int64_t)rows * cols;
+  const std::vector<float> ladder = scale_ladder(m, rows, cols, scale_factor, min_w, min_h, max_w, max_h);
+  // Levels whose pyramid image and integrals exist: the cascade's own ladder, or -- when several cascades share one
+  // prep pass over the same frames -- the union of their ladders (ascending scale).  Level geometry depends on the
+  // scale alone, so the integral layout is the same for every cascade of the group; a level outside this cascade's
+  // own ladder has an empty grid and is never scanned by it.
+  const std::vector<float>& prep = prep_scales ? *prep_scales : ladder;
+  if (prep.empty()) return HC_OK;
+  for (float s : ladder)
+    if (std::find(prep.begin(), prep.end(), s) == prep.end()) return HC_ERR_ARG;
 
   // ---- level geometry + workspace layout
-  for (float sc : ladder) {
+  int first_scanned = -1;
+  for (float sc : prep) {
+    const bool scanned = std::find(ladder.begin(), ladder.end(), sc) != ladder.end();
     DevLevel L{};
     L.scale = sc;
     L.w = rne((float)cols / sc);
     L.h = rne((float)rows / sc);
     L.ystep = sc >= 2.f ? 1 : 2;
-    L.szw_w = std::max(L.w + 1 - m.win_w, 0);
-    L.szw_h = std::max(L.h + 1 - m.win_h, 0);
+    L.szw_w = scanned ? std::max(L.w + 1 - m.win_w, 0) : 0;
+    L.szw_h = scanned ? std::max(L.h + 1 - m.win_h, 0) : 0;
     L.win_w = rne((float)m.win_w * sc);
     L.win_h = rne((float)m.win_h * sc);
     // Column 0 of an integral is the zero column, so the stores of the integral kernels start at
@@ -128,12 +144,16 @@ int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_
     build_resize_table(rows, L.h, p.ytab);
     p.pyr_bytes += align_up((int64_t)L.w * L.h, 64);
     p.int_words += (int64_t)L.int_pitch * (L.h + 1) + 32;
-    p.algorithmic_bytes += 16ll * (L.w + 1) * (L.h + 1);
+    if (scanned) {
+      p.algorithmic_bytes += 16ll * (L.w + 1) * (L.h + 1);
+      if (first_scanned < 0) first_scanned = (int)p.levels.size();
+    }
+    p.scanned.push_back(scanned ? 1 : 0);
     p.levels.push_back(L);
   }
   // stripe rule: the scanned rows are the union of nstripes stripes whose size is
   // derived with truncating divisions -> trailing rows can drop out
-  p.nstripes = (int)std::ceil(p.levels[0].szw_w / 32.0);
+  p.nstripes = first_scanned >= 0 ? (int)std::ceil(p.levels[first_scanned].szw_w / 32.0) : 0;
   for (DevLevel& L : p.levels) {
     const int per = std::max(ceil_div(L.szw_h / L.ystep, std::max(p.nstripes, 1)), 1) * L.ystep;
     L.y_end = std::min(p.nstripes * per, L.szw_h);

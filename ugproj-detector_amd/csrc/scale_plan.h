@@ -18,6 +18,7 @@ struct Plan {
   int nstripes = 0;
 
   std::vector<DevLevel> levels;       // device-visible per-level record
+  std::vector<uint8_t> scanned;       // per level: in this cascade's own ladder (always 1 unless the prep pass is shared)
   std::vector<uint32_t> xtab, ytab;   // resize tables, all levels concatenated: (ofs << 9) | c1
   std::vector<WorkItem> resize_items; // 64x4-pixel tiles
   std::vector<WorkItem> row_items;    // 4 rows per block
@@ -34,8 +35,15 @@ struct Plan {
 
 // Fills `p`. Returns HC_OK; an image smaller than the window or an empty ladder yields a
 // plan with zero levels (detectMultiScale then returns no rectangles).
+// prep_scales (optional): the levels to lay out -- a superset of the cascade's own ladder, ascending -- when
+// several cascades share one pyramid + integral pass (hc_context_configure_shared).
 int build_plan(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h,
-               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p);
+               int max_w, int max_h, int band_rows_ystep1, int band_rows_ystep2, Plan& p,
+               const std::vector<float>* prep_scales = nullptr);
+
+// the f32 scale ladder of the call; empty when the image is smaller than the window
+std::vector<float> scale_ladder(const Model& m, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w,
+                                int max_h);
 
 // (ofs << 9) | c1 for every destination index of a src -> dst exact bilinear resize
 void build_resize_table(int src, int dst, std::vector<uint32_t>& out);
