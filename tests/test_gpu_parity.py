@@ -687,6 +687,7 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_HOST_THREADS": "1", "HC_FUSED_PREP": "0"},
     {"HC_SEG_MAX_BATCH": "0", "HC_SIDE_MAX_BATCH": "0"},  # small batches without band segments / side stream
     {"HC_SEG_TILES": "1"},
+    {"HC_FUSE_VARIANCE": "0", "HC_FUSED_PREP": "1"},    # fused prep kernel, variance factors by the separate k_variance
     {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
     {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
 ])

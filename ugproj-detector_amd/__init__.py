@@ -25,7 +25,8 @@ except ImportError:      # pure C++/ctypes use: the system ROCm runtime is used
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhip_cascade.so")
+# HC_LIB_PATH: A/B experiments with alternative builds of the same library (tools/exp_*.sh); never a different backend
+LIB_PATH = os.environ.get("HC_LIB_PATH") or os.path.join(_HERE, "libhip_cascade.so")
 
 HC_NKERNELS = 5
 TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES, TAP_FACE_MASK, TAP_FACE_GRAY, TAP_FACE_BGR = range(8)

@@ -156,6 +156,7 @@ struct hc_context {
   // k_resize + k_integral_rows + k_integral_cols (fully parallel: 0.07 instead of 0.39 ms for ONE 720p frame).
   // -1: by batch size (fused above fused_min_batch frames), 0: never fused, 1: always fused (HC_FUSED_PREP)
   int fused_prep = -1;
+  bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   double fused_min_batch = 16;   // thresholds below are in 720p-frame equivalents: a 360p frame counts 1/4, a 1080p frame 2.25
   int row_stages = 1;
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
@@ -281,7 +282,11 @@ void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vect
   out.reserve(m.nodes.size());
   auto word = [&](int dx, int dy) {
     const int col = ystep == 1 ? dx : ((dx & 1) * g.half + (dx >> 1));
+#ifdef HC_OFF_BYTES
+    return (uint16_t)((dy * g.pitch + col) * 4);   // byte offsets: the kernel adds them to a byte base (kernels.hip hc_corner_addr)
+#else
     return (uint16_t)(dy * g.pitch + col);
+#endif
   };
   for (const hc::ModelTree& t : m.trees) {
     for (int k = 0; k < t.nnodes; k++) {
@@ -359,7 +364,11 @@ int upload_model(hc_context* c) {
     const int ystep = k + 1;
     c->geom[k] = make_geom(m, ystep, c->band_rows[k]);
     const size_t words = ((size_t)c->geom[k].pitch * c->geom[k].rows + 1) & ~(size_t)1;   // even: 8-byte aligned LDS regions behind the tile
+#ifdef HC_OFF_BYTES
+    if (words * 4 > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS byte offsets");
+#else
     if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
+#endif
     c->tile_words[k] = (int)words;
     // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | 2 queues x band_rows*64 u16 | 3 counters (+pad)
     c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 16;
@@ -474,6 +483,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     const size_t pyr_stride = (size_t)P.pyr_bytes, int_stride = (size_t)P.int_words, grid_stride = (size_t)P.grid_elems;
     if (c->taps_enabled) HIPCHK(hipMemsetAsync(c->d_taps, 0xFE, grid_stride * nframes, s));
     int e;
+    bool fused_variance = false;
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
     // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
     const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
@@ -485,9 +495,13 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       int max_w = 0;
       for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
       // the pyramid bytes only exist as a debug tap in this mode
+      // a context on its own gets its variance factors from the same kernel (no k_variance launch, no second pass
+      // over the integrals); a shared prep pass serves cascades with different windows, which run k_variance each
+      fused_variance = c->fuse_variance && c->followers.empty();
       if ((e = hc::launch_pyramid_integral(s, nframes, (int)P.levels.size(), max_w, d_frames, frame_stride, row_step,
                                            P.rows, P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq,
-                                           int_stride, c->taps_enabled ? c->d_pyr : nullptr, pyr_stride)))
+                                           int_stride, c->taps_enabled ? c->d_pyr : nullptr, pyr_stride,
+                                           fused_variance ? c->d_vnf : nullptr, grid_stride, m.win_w - 2, m.win_h - 2)))
         return set_err(HC_ERR_HIP, std::string("k_pyramid_integral launch: ") + hipGetErrorString((hipError_t)e));
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
     } else {
@@ -505,7 +519,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     }
     if (!c->followers.empty()) HIPCHK(hipEventRecord(c->ev_prep, s));
     if (timed) HIPCHK(hipEventRecord(c->ev[3], s));
-    if ((e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
+    if (!fused_variance &&
+        (e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
@@ -657,6 +672,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
+  if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));

@@ -41,11 +41,14 @@ struct SkinBounds { int32_t lo[3], hi[3]; };
 int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames, size_t frame_stride,
                   size_t row_step, int rows, int cols, const DevLevel* levels, const uint32_t* xtab,
                   const uint32_t* ytab, const WorkItem* items, uint8_t* pyr, size_t pyr_stride);
-// fused resize + row scan + column scan: one workgroup per (level, frame); pyr may be null
+// fused resize + row scan + column scan: one workgroup per (level, frame); pyr may be null.  vnf non-null: the
+// variance factor (A.6a) of every scanned window is produced as well (inner rect norm_w x norm_h, [gy][gx] per level
+// at DevLevel::grid_ofs, frame stride grid_stride) and no k_variance launch is needed.
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
-                            uint8_t* pyr, size_t pyr_stride);
+                            uint8_t* pyr, size_t pyr_stride, float* vnf = nullptr, size_t grid_stride = 0, int norm_w = 0,
+                            int norm_h = 0);
 // FaceDetector::detectFaces pre-steps (face_kernels.hip): BGR -> mask + equalised, masked gray
 int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t frame_stride, size_t row_step, int rows,
                      int cols, const SkinBounds& sb, uint8_t* gray, uint8_t* mask, size_t plane_stride, uint32_t* hist,

@@ -51,6 +51,19 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
   return v;
 }
 
+// A.6a: variance normalisation factor of one window from the sums of its inner rect (normrect):
+// nf = area*valsq - valsum^2 (f64, exact); nf > 0: vnf = (float)(1/sqrt(nf)) kept iff area*(double)vnf < 0.1; else 0
+__device__ __forceinline__ float vnf_from_sums(int valsum, uint32_t valsq, double area) {
+  double nf = area * (double)valsq - (double)valsum * (double)valsum;
+  float out = 0.f;
+  if (nf > 0.) {
+    nf = sqrt(nf);
+    const float v = (float)(1. / nf);
+    if (area * (double)v < 1e-1) out = v;
+  }
+  return out;
+}
+
 // ------------------------------------------------------------------------------------------
 // A.4  pyramid: dst(level, dy, dx) from the ORIGINAL frame, 8.8 x 8.8 fixed point
 // block = 64 x 4 destination pixels
@@ -162,7 +175,8 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
     const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_step, int rows, int cols,
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
     uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
-    size_t pyr_stride, int R, int lds_pitch, int src_pitch) {
+    size_t pyr_stride, int R, int lds_pitch, int src_pitch, float* __restrict__ vnf, size_t grid_stride, int norm_w,
+    int norm_h) {
   extern __shared__ uint32_t rowbuf[];   // [2][R][lds_pitch] row prefixes | [lds_pitch] x table | per wave 2 source rows
   uint32_t* rs = rowbuf;
   uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
@@ -253,6 +267,28 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       }
     }
     __syncthreads();
+    // Phase 3 (A.6a fused in): the variance factor of every window whose inner rect ENDS in this chunk.  Its 8 integral
+    // words are this workgroup's own stores -- the bottom row from this chunk, the top row norm_h rows up -- drained by
+    // the barrier above (s_waitcnt vmcnt(0) precedes it) and never read by this CU before their final value was
+    // written, so they come back from L2 (or L1) current; no other kernel has to re-read the integrals for this.
+    // Uses no LDS: the wavefronts that finish first go on to the next chunk's phase 1.
+    if (vnf && Q && L.nx > 0) {
+      const int ys = L.ystep, gnx = L.nx, gny = L.ny;
+      // window row y = gy*ys has its bottom integral row at y + 1 + norm_h; rows y0+1 .. y0+nr were finished just now
+      int gy_lo = max(y0 - norm_h, 0);
+      gy_lo = (gy_lo + ys - 1) / ys;
+      const int gy_hi = min((y0 + nr - 1 - norm_h) >= 0 ? (y0 + nr - 1 - norm_h) / ys : -1, gny - 1);
+      const int nrows = gy_hi - gy_lo + 1;
+      const double area = (double)(norm_w * norm_h);
+      float* vout = vnf + (size_t)frame * grid_stride + L.grid_ofs;
+      for (int i = threadIdx.x; i < nrows * gnx; i += PI_THREADS) {
+        const int gy = gy_lo + i / gnx, gx = i - (i / gnx) * gnx;
+        const size_t p0 = (size_t)(gy * ys + 1) * pitch + gx * ys + 1, p2 = p0 + (size_t)norm_h * pitch;
+        const int valsum = (int)(S[p0] - S[p0 + norm_w] - S[p2] + S[p2 + norm_w]);
+        const uint32_t valsq = Q[p0] - Q[p0 + norm_w] - Q[p2] + Q[p2 + norm_w];
+        vout[(size_t)gy * gnx + gx] = vnf_from_sums(valsum, valsq, area);
+      }
+    }
   }
 }
 
@@ -262,26 +298,32 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
 __global__ __launch_bounds__(WG_THREADS) void k_variance(
     const DevLevel* __restrict__ levels, const WorkItem* __restrict__ items,
     const uint32_t* __restrict__ sum, const uint32_t* __restrict__ sq, size_t int_stride,
-    int norm_w, int norm_h, float* __restrict__ vnf, size_t grid_stride) {
-  const WorkItem it = load_item(items, blockIdx.x);
+    int norm_w, int norm_h, float* __restrict__ vnf, size_t grid_stride, int nitems, int nframes) {
+  // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  A window reads integral rows 18 (22)
+  // apart, so the rows one workgroup brings in are wanted again by the workgroups a few grid rows further down the
+  // same frame: all workgroups of a frame are therefore placed on ONE XCD (frame = 8 * group + id % 8) instead of
+  // being sprayed over all eight, which made every XCD fetch the same lines (1.6 x the algorithmic read).
+  int item, frame;
+  if (nframes % 8 == 0) {
+    const int id = blockIdx.x, xcd = id & 7, k = id >> 3;
+    item = k % nitems;
+    frame = (k / nitems) * 8 + xcd;
+  } else {
+    item = blockIdx.x % nitems;
+    frame = blockIdx.x / nitems;
+  }
+  const WorkItem it = load_item(items, item);
   const HC_CONST DevLevel& L = as_const(levels)[it.level];
   const int i = it.a + threadIdx.x;
   if (i >= L.nx * L.ny) return;
   const int gy = i / L.nx, gx = i - gy * L.nx;
   const int x = gx * L.ystep + 1, y = gy * L.ystep + 1;       // normrect = (1, 1, win_w-2, win_h-2)
-  const size_t base = (size_t)blockIdx.y * int_stride + L.int_ofs;
+  const size_t base = (size_t)frame * int_stride + L.int_ofs;
   const size_t p0 = base + (size_t)y * L.int_pitch + x, p2 = p0 + (size_t)norm_h * L.int_pitch;
   const int valsum = (int)(sum[p0] - sum[p0 + norm_w] - sum[p2] + sum[p2 + norm_w]);
   const uint32_t valsq = sq[p0] - sq[p0 + norm_w] - sq[p2] + sq[p2 + norm_w];
-  const double area = (double)(norm_w * norm_h);
-  double nf = area * (double)valsq - (double)valsum * (double)valsum;
-  float out = 0.f;
-  if (nf > 0.) {
-    nf = sqrt(nf);
-    const float v = (float)(1. / nf);
-    if (area * (double)v < 1e-1) out = v;
-  }
-  vnf[(size_t)blockIdx.y * grid_stride + L.grid_ofs + (size_t)gy * L.nx + gx] = out;
+  const float out = vnf_from_sums(valsum, valsq, (double)(norm_w * norm_h));
+  vnf[(size_t)frame * grid_stride + L.grid_ofs + (size_t)gy * L.nx + gx] = out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -312,16 +354,38 @@ __device__ __forceinline__ NodeRegs load_node(const HC_CONST DevNode* nodes, int
 
 #define HC_OFF(q, k) (int)(((q)[(k) >> 1] >> (((k)&1) * 16)) & 0xffffu)
 
+// One corner of the LDS tile for the window whose origin word is `base`; corner k of the node's offset table q.
+#ifdef HC_OFF_BYTES
+// DevNode::off holds BYTE offsets (hc_api.cpp build_nodes).  The 16-bit half of the scalar register is selected by the
+// add itself (SDWA source select on an SGPR operand), so forming a corner address costs one VALU instruction and no
+// scalar unpacking (the s_and / s_bfe pair per corner was 12 SALU instructions per stump pair).
+__device__ __forceinline__ int hc_corner_addr(uint32_t packed, int half, int base_bytes) {
+  int r;
+  if (half) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "s"(packed), "v"(base_bytes));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "s"(packed), "v"(base_bytes));
+  return r;
+}
+// absolute LDS byte address of the window origin: the tile's own LDS address folded in once per window, so the SDWA
+// add yields the final address and the load needs no further arithmetic
+typedef const int32_t __attribute__((address_space(3))) * hc_lds_cptr;
+#define HC_LDS_ADDR(tile, base) ((int)(uint32_t)(uintptr_t)(hc_lds_cptr)(tile) + ((base) << 2))
+#define HC_TILE_Q(tile, base, q, k) (*(hc_lds_cptr)(uintptr_t)(uint32_t)hc_corner_addr((q)[(k) >> 1], (k)&1, HC_LDS_ADDR(tile, base)))
+#define HC_TILE_O(tile, base, off) (*(hc_lds_cptr)(uintptr_t)(uint32_t)(HC_LDS_ADDR(tile, base) + (int)(off)))
+#else
+#define HC_TILE_Q(tile, base, q, k) ((tile)[(base) + HC_OFF(q, k)])
+#define HC_TILE_O(tile, base, off) ((tile)[(base) + (off)])
+#endif
+
 __device__ __forceinline__ float feature_value(const int32_t* tile, int base, const NodeRegs& n, float vnf) {
-  const int s0 = tile[base + HC_OFF(n.q0, 0)] - tile[base + HC_OFF(n.q0, 1)] - tile[base + HC_OFF(n.q0, 2)] +
-                 tile[base + HC_OFF(n.q0, 3)];
-  const int s1 = tile[base + HC_OFF(n.q0, 4)] - tile[base + HC_OFF(n.q0, 5)] - tile[base + HC_OFF(n.q0, 6)] +
-                 tile[base + HC_OFF(n.q0, 7)];
+  const int s0 = HC_TILE_Q(tile, base, n.q0, 0) - HC_TILE_Q(tile, base, n.q0, 1) - HC_TILE_Q(tile, base, n.q0, 2) +
+                 HC_TILE_Q(tile, base, n.q0, 3);
+  const int s1 = HC_TILE_Q(tile, base, n.q0, 4) - HC_TILE_Q(tile, base, n.q0, 5) - HC_TILE_Q(tile, base, n.q0, 6) +
+                 HC_TILE_Q(tile, base, n.q0, 7);
   const float w0 = __uint_as_float(n.q1[2]), w1 = __uint_as_float(n.q1[3]), w2 = __uint_as_float(n.q2[0]);
   float ret = w0 * (float)s0 + w1 * (float)s1;
   if (w2 != 0.0f) {   // wave-uniform branch
-    const int s2 = tile[base + HC_OFF(n.q1, 0)] - tile[base + HC_OFF(n.q1, 1)] - tile[base + HC_OFF(n.q1, 2)] +
-                   tile[base + HC_OFF(n.q1, 3)];
+    const int s2 = HC_TILE_Q(tile, base, n.q1, 0) - HC_TILE_Q(tile, base, n.q1, 1) - HC_TILE_Q(tile, base, n.q1, 2) +
+                   HC_TILE_Q(tile, base, n.q1, 3);
     ret += w2 * (float)s2;
   }
   return ret * vnf;
@@ -387,17 +451,17 @@ struct Corners { int a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3; };
 template <int KIND>
 __device__ __forceinline__ Corners<KIND> read_corners(const int32_t* tile, int base, const NodeRegs& n) {
   Corners<KIND> c;
-  c.a0 = tile[base + HC_OFF(n.q0, 0)]; c.a1 = tile[base + HC_OFF(n.q0, 1)];
-  c.a2 = tile[base + HC_OFF(n.q0, 2)]; c.a3 = tile[base + HC_OFF(n.q0, 3)];
-  c.b0 = (KIND == NK_LEFT || KIND == NK_TOP || KIND == NK_DIAG) ? c.a0 : tile[base + HC_OFF(n.q0, 4)];
-  c.b1 = (KIND == NK_RIGHT || KIND == NK_TOP || KIND == NK_ANTIDIAG) ? c.a1 : tile[base + HC_OFF(n.q0, 5)];
-  c.b2 = (KIND == NK_BOTTOM || KIND == NK_LEFT) ? c.a2 : tile[base + HC_OFF(n.q0, 6)];
-  c.b3 = (KIND == NK_BOTTOM || KIND == NK_RIGHT) ? c.a3 : tile[base + HC_OFF(n.q0, 7)];
+  c.a0 = HC_TILE_Q(tile, base, n.q0, 0); c.a1 = HC_TILE_Q(tile, base, n.q0, 1);
+  c.a2 = HC_TILE_Q(tile, base, n.q0, 2); c.a3 = HC_TILE_Q(tile, base, n.q0, 3);
+  c.b0 = (KIND == NK_LEFT || KIND == NK_TOP || KIND == NK_DIAG) ? c.a0 : HC_TILE_Q(tile, base, n.q0, 4);
+  c.b1 = (KIND == NK_RIGHT || KIND == NK_TOP || KIND == NK_ANTIDIAG) ? c.a1 : HC_TILE_Q(tile, base, n.q0, 5);
+  c.b2 = (KIND == NK_BOTTOM || KIND == NK_LEFT) ? c.a2 : HC_TILE_Q(tile, base, n.q0, 6);
+  c.b3 = (KIND == NK_BOTTOM || KIND == NK_RIGHT) ? c.a3 : HC_TILE_Q(tile, base, n.q0, 7);
   if (KIND == NK_ANTIDIAG || KIND == NK_DIAG || KIND == NK_NONE3) {
-    c.c0 = KIND == NK_DIAG ? c.b3 : tile[base + HC_OFF(n.q1, 0)];
-    c.c1 = KIND == NK_ANTIDIAG ? c.b2 : tile[base + HC_OFF(n.q1, 1)];
-    c.c2 = KIND == NK_ANTIDIAG ? c.a2 : tile[base + HC_OFF(n.q1, 2)];
-    c.c3 = KIND == NK_DIAG ? c.a3 : tile[base + HC_OFF(n.q1, 3)];
+    c.c0 = KIND == NK_DIAG ? c.b3 : HC_TILE_Q(tile, base, n.q1, 0);
+    c.c1 = KIND == NK_ANTIDIAG ? c.b2 : HC_TILE_Q(tile, base, n.q1, 1);
+    c.c2 = KIND == NK_ANTIDIAG ? c.a2 : HC_TILE_Q(tile, base, n.q1, 2);
+    c.c3 = KIND == NK_DIAG ? c.a3 : HC_TILE_Q(tile, base, n.q1, 3);
   } else {
     c.c0 = c.c1 = c.c2 = c.c3 = 0;
   }
@@ -423,6 +487,24 @@ __device__ __forceinline__ void stump_run(const int32_t* tile, int base, float v
   // Two stumps per iteration: both nodes arrive in one scalar load and the LDS reads of both are issued
   // before either feature is computed, so a wavefront pays the SMEM and the LDS latency once per pair.
   int t = 0;
+#ifdef HC_NODE_PREFETCH
+  // The NEXT pair's node records are requested before this pair's LDS reads go out: scalar loads and LDS reads
+  // share lgkmcnt, so the wait in front of the arithmetic covers both and the scalar latency no longer sits in
+  // front of the LDS latency (it used to be paid in series once per pair).
+  if (count >= 2) {
+    NodeRegs n0 = load_node(nodes, first), n1 = load_node(nodes, first + 1);
+    for (; t + 2 <= count; t += 2) {                          // wave-uniform trip count
+      const int tn = first + min(t + 2, count - 2);           // last iteration: re-requests its own pair (in range, unused)
+      const NodeRegs m0 = load_node(nodes, tn), m1 = load_node(nodes, tn + 1);
+      const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
+      const Corners<KIND> c1 = read_corners<KIND>(tile, base, n1);
+      __builtin_amdgcn_sched_barrier(0);                      // keep all reads ahead of the arithmetic
+      acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
+      acc += stump_leaf(n1, feature_from_corners<KIND>(c1, n1, vnf));
+      n0 = m0; n1 = m1;
+    }
+  }
+#else
   for (; t + 2 <= count; t += 2) {                            // wave-uniform trip count
     const NodeRegs n0 = load_node(nodes, first + t), n1 = load_node(nodes, first + t + 1);
     const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
@@ -431,6 +513,7 @@ __device__ __forceinline__ void stump_run(const int32_t* tile, int base, float v
     acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
     acc += stump_leaf(n1, feature_from_corners<KIND>(c1, n1, vnf));
   }
+#endif
   if (t < count) {
     const NodeRegs n0 = load_node(nodes, first + t);
     const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
@@ -495,11 +578,11 @@ __device__ __forceinline__ bool eval_stage(const int32_t* tile, int base, float 
 // same double as upstream's sequential accumulation.  Removes the long serial stump chains of
 // the few windows that reach the deep stages.
 __device__ __forceinline__ float feature_value_lane(const int32_t* tile, int base, const DevNode& n, float vnf) {
-  const int s0 = tile[base + n.off[0]] - tile[base + n.off[1]] - tile[base + n.off[2]] + tile[base + n.off[3]];
-  const int s1 = tile[base + n.off[4]] - tile[base + n.off[5]] - tile[base + n.off[6]] + tile[base + n.off[7]];
+  const int s0 = HC_TILE_O(tile, base, n.off[0]) - HC_TILE_O(tile, base, n.off[1]) - HC_TILE_O(tile, base, n.off[2]) + HC_TILE_O(tile, base, n.off[3]);
+  const int s1 = HC_TILE_O(tile, base, n.off[4]) - HC_TILE_O(tile, base, n.off[5]) - HC_TILE_O(tile, base, n.off[6]) + HC_TILE_O(tile, base, n.off[7]);
   float ret = n.w[0] * (float)s0 + n.w[1] * (float)s1;
   if (n.w[2] != 0.0f) {
-    const int s2 = tile[base + n.off[8]] - tile[base + n.off[9]] - tile[base + n.off[10]] + tile[base + n.off[11]];
+    const int s2 = HC_TILE_O(tile, base, n.off[8]) - HC_TILE_O(tile, base, n.off[9]) - HC_TILE_O(tile, base, n.off[10]) + HC_TILE_O(tile, base, n.off[11]);
     ret += n.w[2] * (float)s2;
   }
   return ret * vnf;
@@ -734,6 +817,72 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         // more stage to all of them, a static split leaves wavefronts idle behind the unlucky one); a window
         // runs through all remaining stages one stage at a time, the stage's weak classifiers spread over
         // the 64 lanes.
+#ifdef HC_SPARSE_STAGE_MAJOR
+        if (!TREE) {
+          // Stage-major: wavefront w takes windows w, w + NW, .. (at most SPW) and carries ALL of them through a stage
+          // before the next one: the per-lane node records of a 64-stump chunk are fetched from L2 once per chunk and
+          // stage instead of once per chunk, stage AND window, the windows of a chunk are independent (their LDS reads
+          // overlap), and a window's partial sums stay in registers until the stage ends (one wave reduction per
+          // window and stage).  The list of a wavefront's live windows is wave-private LDS (no barrier: LDS
+          // operations of one wave execute in order).
+          constexpr int SPW = 8;
+          uint16_t* wl = qout + wave * SPW;                       // this stage's output queue is unused from here on
+          for (int i0 = 0; i0 < n; i0 += NW * SPW) {              // one round unless HC_SPARSE_MAX was raised
+          int nl = 0;
+          for (int i = i0 + wave; i < min(n, i0 + NW * SPW); i += NW) { if (lane == 0) wl[nl] = qin[i]; nl++; }
+          __builtin_amdgcn_wave_barrier();
+          for (int ss = s; ss < A.nstages && nl > 0; ss++) {
+            const int sfirst2 = stages[ss].first, scount2 = stages[ss].count;
+            const double sthr2 = (double)stages[ss].thr;
+            double part[SPW];
+#pragma unroll
+            for (int k = 0; k < SPW; k++) part[k] = 0.0;
+            for (int t0 = 0; t0 < scount2; t0 += 64) {
+              const int t = t0 + lane;
+              const bool act = t < scount2;
+              const DevNode nd = A.nodes[sfirst2 + min(t, scount2 - 1)];
+              const float la = __uint_as_float(nd.a), lb = __uint_as_float(nd.b);
+#pragma unroll
+              for (int k = 0; k < SPW; k++) {
+                if (k < nl) {                                     // wave-uniform
+                  const int pos = wl[k];
+                  const int wbase = (pos >> 6) * ys * G.pitch + (pos & 63);
+                  const float v = feature_value_lane(tile, wbase, nd, vnf_t[pos]);
+                  part[k] += act ? (double)(v < nd.thr ? la : lb) : 0.0;
+                }
+              }
+            }
+            int keep = 0;
+#pragma unroll
+            for (int k = 0; k < SPW; k++) {
+              if (k < nl) {
+                const int pos = wl[k];
+                const bool ok = !(wave_sum_f64(part[k]) < sthr2);  // uniform
+                if (ok) {
+                  if (lane == 0) wl[keep] = (uint16_t)pos;         // keep <= k: never overwrites an unread entry
+                  keep++;
+                } else if (A.taps && lane == 0) {
+                  A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)ss;
+                }
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            nl = keep;
+          }
+          if (lane == 0)
+            for (int k = 0; k < nl; k++) {                        // passed every stage
+              const int pos = wl[k];
+              const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
+              if (A.cand_cap) {
+                const unsigned int slot = atomicAdd(A.cand_count, 1u);
+                if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)wy << 16) | (unsigned long long)wx;
+              }
+              if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)A.nstages;
+            }
+          __builtin_amdgcn_wave_barrier();
+          }
+        } else
+#endif
         for (;;) {
           // all 64 lanes add 1: the counter moves in steps of 64 per grab, any lane's ticket >> 6 is the index
           const int i = __builtin_amdgcn_readfirstlane(atomicAdd(cout, 1)) >> 6;
@@ -881,7 +1030,7 @@ int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
-                            uint8_t* pyr, size_t pyr_stride) {
+                            uint8_t* pyr, size_t pyr_stride, float* vnf, size_t grid_stride, int norm_w, int norm_h) {
   if (nlevels == 0 || nframes == 0) return 0;
   const int lds_pitch = (max_w + 63) & ~63;
   const int src_pitch = (cols + 3 + 3) & ~3;     // staged source row: dword granular, >= cols
@@ -896,7 +1045,8 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
 #define HC_PI(C)                                                                                                  \
   hipLaunchKernelGGL((k_pyramid_integral<C>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
-                     levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch)
+                     levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
+                     norm_w, norm_h)
   if (max_w <= 2 * PI_THREADS) HC_PI(2);
   else if (max_w <= 4 * PI_THREADS) HC_PI(4);
   else if (max_w <= 8 * PI_THREADS) HC_PI(8);
@@ -929,8 +1079,8 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride) {
   if (nitems == 0 || nframes == 0) return 0;
-  hipLaunchKernelGGL(k_variance, dim3(nitems, nframes), dim3(WG_THREADS), 0, st, levels, items, sum, sq,
-                     int_stride, norm_w, norm_h, vnf, grid_stride);
+  hipLaunchKernelGGL(k_variance, dim3((unsigned)nitems * (unsigned)nframes), dim3(WG_THREADS), 0, st, levels, items, sum, sq,
+                     int_stride, norm_w, norm_h, vnf, grid_stride, nitems, nframes);
   HC_LAUNCH_CHECK();
   return 0;
 }
