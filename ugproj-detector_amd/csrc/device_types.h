@@ -57,17 +57,21 @@ struct DevStageKinds { uint16_t end[NK_COUNT]; };
 
 // One weak-classifier node, offsets pre-resolved for a TileGeom.
 struct DevNode {
-  uint16_t off[12];   // LDS word offsets of 3 rects x 4 corners relative to the window origin word
+  uint16_t off[12];   // LDS byte offsets of 3 rects x 4 corners relative to the window origin
   float w[3];         // raw rect weights (w[2] == 0 -> two-rect feature)
   float thr;
-  uint32_t a, b;      // stump: f32 bits of left/right leaf; tree: int32 child codes (<=0 leaf, >0 node)
+  uint32_t a, b;      // stump in a stage with DevStage::exact == 0: f32 bits of the left / right leaf;
+                      // stump in an exact stage: low / high word of the f64 (double)left - (double)right;
+                      // tree: int32 child codes (<= 0 leaf, > 0 node)
 };
 static_assert(sizeof(DevNode) == 48, "DevNode layout");
 
 // first/count in nodes (stump) or trees (tree); exact != 0: the f64 sum of any subset of the
 // stage's leaf values is exact in any order (sparse stump-parallel mode is then bit-identical);
 // exact == 2: the same holds for every later stage as well
-struct DevStage { int32_t first, count; float thr; int32_t exact; };
+// bsum: exact stump stages only -- the f64 sum of the right leaves, the value every stage sum starts from (0 otherwise)
+struct DevStage { int32_t first, count; float thr; int32_t exact; double bsum; };
+static_assert(sizeof(DevStage) == 24, "DevStage layout");
 struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };
 
 }  // namespace hc

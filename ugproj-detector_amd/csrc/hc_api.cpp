@@ -282,7 +282,7 @@ void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vect
   out.reserve(m.nodes.size());
   auto word = [&](int dx, int dy) {
     const int col = ystep == 1 ? dx : ((dx & 1) * g.half + (dx >> 1));
-#ifdef HC_OFF_BYTES
+#ifndef HC_OFF_WORDS
     return (uint16_t)((dy * g.pitch + col) * 4);   // byte offsets: the kernel adds them to a byte base (kernels.hip hc_corner_addr)
 #else
     return (uint16_t)(dy * g.pitch + col);
@@ -354,7 +354,9 @@ bool stage_sum_is_exact(const hc::Model& m, const hc::ModelStage& s) {
     if (u > 0x1p60L) return false;
     units += u;
   }
-  return units < 0x1p53L;
+  // The device also forms bsum = sum(right) and adds [v < thr] * (left - right) per stump: every partial sum of that is
+  // bounded by sum |right| + sum (|left| + |right|) <= 2 * sum |leaf|, so twice the plain bound keeps all of it exact.
+  return 2 * units < 0x1p53L;
 }
 
 int upload_model(hc_context* c) {
@@ -364,7 +366,7 @@ int upload_model(hc_context* c) {
     const int ystep = k + 1;
     c->geom[k] = make_geom(m, ystep, c->band_rows[k]);
     const size_t words = ((size_t)c->geom[k].pitch * c->geom[k].rows + 1) & ~(size_t)1;   // even: 8-byte aligned LDS regions behind the tile
-#ifdef HC_OFF_BYTES
+#ifndef HC_OFF_WORDS
     if (words * 4 > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS byte offsets");
 #else
     if (words > 65535) return set_err(HC_ERR_UNSUPPORTED, "window too large for 16-bit LDS offsets");
@@ -383,6 +385,24 @@ int upload_model(hc_context* c) {
     d.count = s.ntrees;
     d.thr = s.thr;
     d.exact = stage_sum_is_exact(m, s) ? 1 : 0;
+    d.bsum = 0.0;
+    if (m.is_stump() && d.exact) {
+      // leaf accumulation as bsum + sum([v < thr] * (left - right)), all in exact f64 (kernels.hip stump_acc)
+      long double bs = 0;
+      for (int i = 0; i < s.ntrees; i++) {
+        const hc::ModelTree& t = m.trees[s.first_tree + i];
+        const double left = (double)m.leaves[t.first_leaf], right = (double)m.leaves[t.first_leaf + 1];
+        const double diff = left - right;
+        bs += right;
+        uint64_t bits;
+        memcpy(&bits, &diff, 8);
+        for (int g = 0; g < 2; g++) {
+          nd[g][t.first_node].a = (uint32_t)bits;
+          nd[g][t.first_node].b = (uint32_t)(bits >> 32);
+        }
+      }
+      d.bsum = (double)bs;
+    }
     st.push_back(d);
     if (m.is_stump()) {
       // Stumps of a stage may be regrouped by kind only when the stage's f64 sum is exact in any order

@@ -355,7 +355,7 @@ __device__ __forceinline__ NodeRegs load_node(const HC_CONST DevNode* nodes, int
 #define HC_OFF(q, k) (int)(((q)[(k) >> 1] >> (((k)&1) * 16)) & 0xffffu)
 
 // One corner of the LDS tile for the window whose origin word is `base`; corner k of the node's offset table q.
-#ifdef HC_OFF_BYTES
+#ifndef HC_OFF_WORDS
 // DevNode::off holds BYTE offsets (hc_api.cpp build_nodes).  The 16-bit half of the scalar register is selected by the
 // add itself (SDWA source select on an SGPR operand), so forming a corner address costs one VALU instruction and no
 // scalar unpacking (the s_and / s_bfe pair per corner was 12 SALU instructions per stump pair).
@@ -477,8 +477,15 @@ __device__ __forceinline__ float feature_from_corners(const Corners<KIND>& c, co
   return ret * vnf;
 }
 
-__device__ __forceinline__ double stump_leaf(const NodeRegs& n, float v) {
-  return (double)(v < __uint_as_float(n.q2[1]) ? __uint_as_float(n.q2[2]) : __uint_as_float(n.q2[3]));
+// Leaf accumulation of a stump in a stage whose f64 sums are exact in any order (DevStage::exact).  The host stores
+// d = (double)left - (double)right in the node (a = low word, b = high word) and starts every stage sum at
+// bsum = sum of the right leaves, so sum(leaf) = bsum + sum([v < thr] * d): the f32 select, its two scalar-to-vector
+// moves and the f32 -> f64 conversion become one select of the high word of 0.0 / 1.0 and one exact FMA
+// (d * c is exact for c in {0, 1}, so fma(d, c, acc) rounds exactly like acc + leaf: not at all, by the proof).
+__device__ __forceinline__ void stump_acc(const NodeRegs& n, float v, double& acc) {
+  const double d = __hiloint2double((int)n.q2[3], (int)n.q2[2]);
+  const double c = __hiloint2double(v < __uint_as_float(n.q2[1]) ? 0x3ff00000 : 0, 0);
+  acc = __builtin_fma(d, c, acc);
 }
 
 template <int KIND>
@@ -487,43 +494,24 @@ __device__ __forceinline__ void stump_run(const int32_t* tile, int base, float v
   // Two stumps per iteration: both nodes arrive in one scalar load and the LDS reads of both are issued
   // before either feature is computed, so a wavefront pays the SMEM and the LDS latency once per pair.
   int t = 0;
-#ifdef HC_NODE_PREFETCH
-  // The NEXT pair's node records are requested before this pair's LDS reads go out: scalar loads and LDS reads
-  // share lgkmcnt, so the wait in front of the arithmetic covers both and the scalar latency no longer sits in
-  // front of the LDS latency (it used to be paid in series once per pair).
-  if (count >= 2) {
-    NodeRegs n0 = load_node(nodes, first), n1 = load_node(nodes, first + 1);
-    for (; t + 2 <= count; t += 2) {                          // wave-uniform trip count
-      const int tn = first + min(t + 2, count - 2);           // last iteration: re-requests its own pair (in range, unused)
-      const NodeRegs m0 = load_node(nodes, tn), m1 = load_node(nodes, tn + 1);
-      const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
-      const Corners<KIND> c1 = read_corners<KIND>(tile, base, n1);
-      __builtin_amdgcn_sched_barrier(0);                      // keep all reads ahead of the arithmetic
-      acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
-      acc += stump_leaf(n1, feature_from_corners<KIND>(c1, n1, vnf));
-      n0 = m0; n1 = m1;
-    }
-  }
-#else
   for (; t + 2 <= count; t += 2) {                            // wave-uniform trip count
     const NodeRegs n0 = load_node(nodes, first + t), n1 = load_node(nodes, first + t + 1);
     const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
     const Corners<KIND> c1 = read_corners<KIND>(tile, base, n1);
     __builtin_amdgcn_sched_barrier(0);                        // keep all reads ahead of the arithmetic
-    acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
-    acc += stump_leaf(n1, feature_from_corners<KIND>(c1, n1, vnf));
+    stump_acc(n0, feature_from_corners<KIND>(c0, n0, vnf), acc);
+    stump_acc(n1, feature_from_corners<KIND>(c1, n1, vnf), acc);
   }
-#endif
   if (t < count) {
     const NodeRegs n0 = load_node(nodes, first + t);
     const Corners<KIND> c0 = read_corners<KIND>(tile, base, n0);
-    acc += stump_leaf(n0, feature_from_corners<KIND>(c0, n0, vnf));
+    stump_acc(n0, feature_from_corners<KIND>(c0, n0, vnf), acc);
   }
 }
 
 __device__ __forceinline__ bool stage_passes_kinds(const int32_t* tile, int base, float vnf, const HC_CONST DevStage& st,
                                                    const HC_CONST DevStageKinds& kd, const HC_CONST DevNode* nodes) {
-  double acc = 0.0;
+  double acc = st.bsum;                                    // the right leaves of every stump; stump_acc adds [v < thr] * (left - right)
   const int first = st.first;
   const float sthr = st.thr;
   const int e0 = kd.end[0], e1 = kd.end[1], e2 = kd.end[2], e3 = kd.end[3], e4 = kd.end[4], e5 = kd.end[5],
@@ -592,22 +580,24 @@ __device__ __forceinline__ float feature_value_lane(const int32_t* tile, int bas
 // pattern of wave_scan_u32 on the two halves of the double; lane 63 ends up with the total, which
 // is then broadcast.  Only used for stages whose sum is exact in any order, so the association
 // chosen here cannot change the result.
-#define HC_DPP_F64(v, CTRL, ROWMASK)                                                                   \
-  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false),      \
-                   __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false))
+#define HC_DPP_F64(v, CTRL, ROWMASK, BC)                                                               \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, BC),         \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, BC))
 __device__ __forceinline__ double wave_sum_f64(double v) {
-  v += HC_DPP_F64(v, 0x111, 0xF);   // row_shr:1  (lanes shifted in from outside the row read +0.0)
-  v += HC_DPP_F64(v, 0x112, 0xF);   // row_shr:2
-  v += HC_DPP_F64(v, 0x114, 0xF);   // row_shr:4
-  v += HC_DPP_F64(v, 0x118, 0xF);   // row_shr:8
-  v += HC_DPP_F64(v, 0x142, 0xA);   // row_bcast:15 -> rows 1,3
-  v += HC_DPP_F64(v, 0x143, 0xC);   // row_bcast:31 -> rows 2,3
+  // row_shr with every row enabled: bound_ctrl makes the lanes shifted in from outside the row read +0.0 by
+  // themselves, so the destination needs no zero-initialisation (two v_mov fewer per step)
+  v += HC_DPP_F64(v, 0x111, 0xF, true);    // row_shr:1
+  v += HC_DPP_F64(v, 0x112, 0xF, true);    // row_shr:2
+  v += HC_DPP_F64(v, 0x114, 0xF, true);    // row_shr:4
+  v += HC_DPP_F64(v, 0x118, 0xF, true);    // row_shr:8
+  v += HC_DPP_F64(v, 0x142, 0xA, false);   // row_bcast:15 -> rows 1,3 (rows 0,2 keep the 0 of `old`)
+  v += HC_DPP_F64(v, 0x143, 0xC, false);   // row_bcast:31 -> rows 2,3
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 template <bool TREE>
 __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int base, float vnf, int first, int count,
-                                                    float sthr, int lane, const DevNode* __restrict__ nodes,
+                                                    float sthr, double bsum, int lane, const DevNode* __restrict__ nodes,
                                                     const DevTree* __restrict__ trees,
                                                     const float* __restrict__ leaves) {
   double part = 0.0;
@@ -615,7 +605,8 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
     if (!TREE) {
       const DevNode n = nodes[first + t];
       const float v = feature_value_lane(tile, base, n, vnf);
-      part += (double)(v < n.thr ? __uint_as_float(n.a) : __uint_as_float(n.b));
+      // exact stage: a/b hold d = left - right as an f64, the stage sum starts at bsum (see stump_acc)
+      part = __builtin_fma(__hiloint2double((int)n.b, (int)n.a), __hiloint2double(v < n.thr ? 0x3ff00000 : 0, 0), part);
     } else {
       const DevTree T = trees[first + t];
       int at = 0;
@@ -627,7 +618,7 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
       part += (double)leaves[T.first_leaf - at];
     }
   }
-  return !(wave_sum_f64(part) < (double)sthr);
+  return !(wave_sum_f64(part) + bsum < (double)sthr);   // bsum is 0 for tree stages
 }
 
 // LDS layout of k_cascade: [ tile: tile_words x i32 ][ vnf: ROWS*64 x f32 ][ 2 queues: ROWS*64 x u16 each ][ 3 counters ]
@@ -817,72 +808,6 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         // more stage to all of them, a static split leaves wavefronts idle behind the unlucky one); a window
         // runs through all remaining stages one stage at a time, the stage's weak classifiers spread over
         // the 64 lanes.
-#ifdef HC_SPARSE_STAGE_MAJOR
-        if (!TREE) {
-          // Stage-major: wavefront w takes windows w, w + NW, .. (at most SPW) and carries ALL of them through a stage
-          // before the next one: the per-lane node records of a 64-stump chunk are fetched from L2 once per chunk and
-          // stage instead of once per chunk, stage AND window, the windows of a chunk are independent (their LDS reads
-          // overlap), and a window's partial sums stay in registers until the stage ends (one wave reduction per
-          // window and stage).  The list of a wavefront's live windows is wave-private LDS (no barrier: LDS
-          // operations of one wave execute in order).
-          constexpr int SPW = 8;
-          uint16_t* wl = qout + wave * SPW;                       // this stage's output queue is unused from here on
-          for (int i0 = 0; i0 < n; i0 += NW * SPW) {              // one round unless HC_SPARSE_MAX was raised
-          int nl = 0;
-          for (int i = i0 + wave; i < min(n, i0 + NW * SPW); i += NW) { if (lane == 0) wl[nl] = qin[i]; nl++; }
-          __builtin_amdgcn_wave_barrier();
-          for (int ss = s; ss < A.nstages && nl > 0; ss++) {
-            const int sfirst2 = stages[ss].first, scount2 = stages[ss].count;
-            const double sthr2 = (double)stages[ss].thr;
-            double part[SPW];
-#pragma unroll
-            for (int k = 0; k < SPW; k++) part[k] = 0.0;
-            for (int t0 = 0; t0 < scount2; t0 += 64) {
-              const int t = t0 + lane;
-              const bool act = t < scount2;
-              const DevNode nd = A.nodes[sfirst2 + min(t, scount2 - 1)];
-              const float la = __uint_as_float(nd.a), lb = __uint_as_float(nd.b);
-#pragma unroll
-              for (int k = 0; k < SPW; k++) {
-                if (k < nl) {                                     // wave-uniform
-                  const int pos = wl[k];
-                  const int wbase = (pos >> 6) * ys * G.pitch + (pos & 63);
-                  const float v = feature_value_lane(tile, wbase, nd, vnf_t[pos]);
-                  part[k] += act ? (double)(v < nd.thr ? la : lb) : 0.0;
-                }
-              }
-            }
-            int keep = 0;
-#pragma unroll
-            for (int k = 0; k < SPW; k++) {
-              if (k < nl) {
-                const int pos = wl[k];
-                const bool ok = !(wave_sum_f64(part[k]) < sthr2);  // uniform
-                if (ok) {
-                  if (lane == 0) wl[keep] = (uint16_t)pos;         // keep <= k: never overwrites an unread entry
-                  keep++;
-                } else if (A.taps && lane == 0) {
-                  A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)ss;
-                }
-              }
-            }
-            __builtin_amdgcn_wave_barrier();
-            nl = keep;
-          }
-          if (lane == 0)
-            for (int k = 0; k < nl; k++) {                        // passed every stage
-              const int pos = wl[k];
-              const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
-              if (A.cand_cap) {
-                const unsigned int slot = atomicAdd(A.cand_count, 1u);
-                if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)wy << 16) | (unsigned long long)wx;
-              }
-              if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)A.nstages;
-            }
-          __builtin_amdgcn_wave_barrier();
-          }
-        } else
-#endif
         for (;;) {
           // all 64 lanes add 1: the counter moves in steps of 64 per grab, any lane's ticket >> 6 is the index
           const int i = __builtin_amdgcn_readfirstlane(atomicAdd(cout, 1)) >> 6;
@@ -893,8 +818,8 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           const float v = vnf_t[pos];
           int ss = s;
           for (; ss < A.nstages; ss++)
-            if (!stage_passes_sparse<TREE>(tile, base, v, stages[ss].first, stages[ss].count, stages[ss].thr, lane,
-                                           A.nodes, A.trees, A.leaves))
+            if (!stage_passes_sparse<TREE>(tile, base, v, stages[ss].first, stages[ss].count, stages[ss].thr, stages[ss].bsum,
+                                           lane, A.nodes, A.trees, A.leaves))
               break;
           if (lane == 0) {
             if (ss == A.nstages && A.cand_cap) {                  // A.6c: raw candidate (cap 0: truncated-cascade timing runs)
@@ -913,7 +838,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           const int pos = qin[i];
           const int wy = gy0 + (pos >> 6), wx = gx0 + (pos & 63);
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
-          const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_t[pos], sfirst, scount, sthr,
+          const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_t[pos], sfirst, scount, sthr, stages[s].bsum,
                                                     lane, A.nodes, A.trees, A.leaves);
           if (lane == 0) {
             if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
@@ -954,6 +879,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             const int q = chunk * (k - 1) + j - 1;
             part += (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lane];
           }
+          part += stages[s].bsum;                                 // stage_partial_kinds sums [v < thr] * (left - right) only
           const bool ok = !(part < (double)sthr);
           const bool surv = active && ok;
           const unsigned long long sm = __ballot(surv);
