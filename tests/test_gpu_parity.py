@@ -683,6 +683,7 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_BAND_ROWS1": "8", "HC_BAND_ROWS2": "16"},
     {"HC_BAND_ROWS1": "32"},
     {"HC_ROW_STAGES": "3", "HC_SPARSE_MAX": "0"},       # never sparse, three row-form stages
+    {"HC_ROW_STAGES": "1"},                             # only stage 0 in row form (the round-1 default)
     {"HC_SPARSE_MAX": "512"},                           # always sparse once a tile has survivors
     {"HC_HOST_THREADS": "1", "HC_FUSED_PREP": "0"},
     {"HC_SEG_MAX_BATCH": "0", "HC_SIDE_MAX_BATCH": "0"},  # small batches without band segments / side stream

@@ -158,7 +158,7 @@ struct hc_context {
   int fused_prep = -1;
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   double fused_min_batch = 16;   // thresholds below are in 720p-frame equivalents: a 360p frame counts 1/4, a 1080p frame 2.25
-  int row_stages = 1;
+  int row_stages = 2;            // stages 0 and 1 in row form (conflict-free LDS reads while 88 % of the windows are alive)
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
 
   // device.  d_frames, d_color, d_pyr and d_taps are allocated on first use: the device-resident
@@ -373,7 +373,12 @@ int upload_model(hc_context* c) {
 #endif
     c->tile_words[k] = (int)words;
     // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | 2 queues x band_rows*64 u16 | 3 counters (+pad)
+#ifndef HC_PLAIN_QUEUES
+    // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | bank matrix + survivor list, band_rows*64 u16 each | 32 counter words + ticket
+    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 136;
+#else
     c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 16;
+#endif
     build_nodes(m, c->geom[k], ystep, nd[k]);
   }
   std::vector<hc::DevStage> st;

@@ -621,7 +621,8 @@ __device__ __forceinline__ bool stage_passes_sparse(const int32_t* tile, int bas
   return !(wave_sum_f64(part) + bsum < (double)sthr);   // bsum is 0 for tree stages
 }
 
-// LDS layout of k_cascade: [ tile: tile_words x i32 ][ vnf: ROWS*64 x f32 ][ 2 queues: ROWS*64 x u16 each ][ 3 counters ]
+// LDS layout of k_cascade: [ tile: tile_words x i32 ][ vnf: ROWS*64 x f32 ][ bank matrix: ROWS*64 x u16 ][ survivor list: ROWS*64 x u16 ]
+//                           [ 32 per-bank counter words + sparse-finish ticket ]   (-DHC_PLAIN_QUEUES: two plain queues + 3 counters, the round-1 form)
 //
 // Workgroup = 4 wavefronts = one band of ROWS grid rows of one level of one frame.  It walks
 // the band left to right in steps of TILE_POS positions; per step it stages the
@@ -663,8 +664,29 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
   extern __shared__ int32_t smem[];
   int32_t* tile = smem;
   float* vnf_t = (float*)(smem + A.tile_words);                 // variance factor of every window of the tile
+#ifndef HC_PLAIN_QUEUES
+  // Survivor lists ordered by LDS bank.  Every corner read of a window is tile[base + off] with `off` uniform over
+  // the wavefront, so which lanes of a 32-lane group collide on a bank is decided by base & 31 alone -- for every
+  // read of every weak classifier of the stage.  A window that passes a stage is appended to column r = base & 31
+  // of a [layer][32] matrix (one LDS atomic on counter r; a tile has exactly 2 * ROWS windows per residue, so
+  // TILE_WIN entries always suffice).  Before the next stage the matrix is copied, layer by layer and skipping the
+  // holes, into a dense list: every complete layer becomes one aligned run of 32 entries with 32 different banks,
+  // i.e. a half-wavefront whose LDS reads are conflict-free; only the ragged last layers still collide.
+  uint16_t* bankm = (uint16_t*)(vnf_t + TILE_WIN);              // [layer][32] survivors of the running stage
+  uint16_t* list = bankm + TILE_WIN;                            // dense, bank-ordered input list of the running stage
+  // 32 per-bank counters; the two alternating sets share a word (low / high 16 bits); word 32: sparse-finish ticket
+  unsigned int* cres = (unsigned int*)(list + TILE_WIN);
+  int* const ticket = (int*)(cres + 32);
+  uint16_t* const queue = list;                                 // cooperative-stage scratch lives behind the list's first 256 entries
+#define HC_APPEND(POS, BASE, SHOUT)                                                                              \
+  do {                                                                                                           \
+    const int r_ = (BASE) & 31;                                                                                  \
+    bankm[((atomicAdd(&cres[r_], 1u << (SHOUT)) >> (SHOUT)) & 0xffffu) * 32 + r_] = (uint16_t)(POS);            \
+  } while (0)
+#else
   uint16_t* queue = (uint16_t*)(vnf_t + TILE_WIN);              // queue[2][TILE_WIN]
   int* cnt = (int*)(queue + 2 * TILE_WIN);                      // three rotating counters
+#endif
   // Dispatch order: frame is the FAST grid dimension, bands (largest levels first) the slow one,
   // so the long-running bands of every frame start first and the tail of the launch is made of
   // the smallest bands.  With a batch that is a multiple of 8, workgroups b and b + nframes
@@ -735,7 +757,11 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
     __syncthreads();              // everybody is done with the previous tile and its queues
     PH_MARK(8);
     fill_tile<NW>(tile, I, L, G, ys, x0, y0, wave, lane);
+#ifndef HC_PLAIN_QUEUES
+    if (threadIdx.x < 33) cres[threadIdx.x] = 0;
+#else
     if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+#endif
     PH_MARK(0);
     __syncthreads();
     PH_MARK(9);
@@ -774,6 +800,9 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         if (A.taps && surv && !ok) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)s;
         surv = surv && ok;
       }
+#ifndef HC_PLAIN_QUEUES
+      if (surv) HC_APPEND(rr * TILE_POS + lane, base, 0);
+#else
       const unsigned long long sm = __ballot(surv);
       if (sm) {
         int off = 0;
@@ -781,6 +810,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         off = __builtin_amdgcn_readfirstlane(off);
         if (surv) queue[off + __popcll(sm & lt_mask)] = (uint16_t)(rr * TILE_POS + lane);
       }
+#endif
     }
     PH_MARK(1);
     __syncthreads();
@@ -791,6 +821,50 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
     // three slots so that the slot zeroed during a stage is neither the one read nor the one
     // being appended to.
     int s = row_stages;
+#ifndef HC_PLAIN_QUEUES
+    // Step t = s - row_stages: the windows that passed the previous stage sit in bankm, counted per bank in counter
+    // half t & 1; they are first copied into `list`, then stage s runs over the list and appends its own survivors
+    // to bankm / half (t + 1) & 1.
+    for (;; s++) {
+      const int t = s - row_stages;
+      const int sh_in = (t & 1) * 16, sh_out = 16 - sh_in;
+      const int kr = (int)((cres[lane & 31] >> sh_in) & 0xffffu);   // entries in this lane's bank column
+      // every wavefront derives the same layer prefix: lane j ends up with s_mine = entries in layers < j
+      int n = 0, s_mine = 0, nlayers = 0;
+      for (;; nlayers++) {                                          // uniform
+        const unsigned int lm = (unsigned int)__ballot(kr > nlayers);   // lanes 0..31: one per bank
+        if (!lm) break;
+        if (lane == nlayers) s_mine = n;
+        n += __popc(lm);
+      }
+      if (n == 0) break;                                        // uniform
+      for (int j0 = wave * 2; j0 < nlayers; j0 += NW * 2) {     // one layer per half-wavefront
+        const int s0 = __builtin_amdgcn_readlane(s_mine, j0), s1 = __builtin_amdgcn_readlane(s_mine, min(j0 + 1, 63));
+        const int jl = j0 + (lane >> 5), r = lane & 31;
+        const bool have = jl < kr;
+        const unsigned long long hm = __ballot(have);
+        const unsigned int half = (unsigned int)(lane < 32 ? hm : (hm >> 32));
+        if (have) list[(lane < 32 ? s0 : s1) + __popc(half & ((1u << r) - 1u))] = bankm[jl * 32 + r];
+      }
+      PH_MARK(4);
+      __syncthreads();
+      PH_MARK(2);
+      const uint16_t* qin = list;
+      if (s == A.nstages) {                                     // the list holds the accepted windows
+        for (int i = threadIdx.x; i < n; i += NTHREADS) {       // A.6c: raw candidates
+          const int pos = qin[i];
+          const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
+          if (A.cand_cap) {
+            const unsigned int slot = atomicAdd(A.cand_count, 1u);
+            if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+          }
+          if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
+        }
+        break;
+      }
+      if (threadIdx.x < 32) atomicAnd(&cres[threadIdx.x], 0xffffu << sh_out);   // every wave has read this half
+      int* const cout = ticket;
+#else
     for (; s < A.nstages; s++) {
       const int t = s - row_stages;
       const int n = cnt[t % 3];
@@ -799,6 +873,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       uint16_t* qout = queue + ((t + 1) & 1) * TILE_WIN;
       int* cout = &cnt[(t + 1) % 3];
       if (threadIdx.x == 0) cnt[(t + 2) % 3] = 0;
+#endif
       const int sfirst = stages[s].first, scount = stages[s].count;
       const float sthr = stages[s].thr;
       if (n <= A.sparse_max && stages[s].exact >= 2) {
@@ -841,23 +916,39 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           const bool ok = stage_passes_sparse<TREE>(tile, base, vnf_t[pos], sfirst, scount, sthr, stages[s].bsum,
                                                     lane, A.nodes, A.trees, A.leaves);
           if (lane == 0) {
+#ifndef HC_PLAIN_QUEUES
+            if (ok) HC_APPEND(pos, base, sh_out);
+#else
             if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
+#endif
             else if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
           }
         }
+#ifndef HC_PLAIN_QUEUES
+      } else if (!TREE && ROWS >= 16 && stages[s].exact && ((n + 63) >> 6) * 2 <= NW && ((n + 63) >> 6) <= 3) {   // three scratch slots
+#else
       } else if (!TREE && ROWS >= 16 && stages[s].exact && ((n + 63) >> 6) * 2 <= NW) {
+#endif
         // Cooperative mode: the survivors fill at most NW/2 wavefronts, so the stage's critical path -- every
         // stump in sequence on one wavefront while the others wait at the barrier -- is cut by giving each
         // 64-window chunk to k = 2 or 4 wavefronts that evaluate 1/k of the stumps each.  Partial sums meet
         // in LDS (the unused tails of the two queues); legal because the stage's f64 sum is order-free.
         const int chunks = (n + 63) >> 6;
+#ifndef HC_PLAIN_QUEUES
+        const int k = chunks == 1 && NW >= 4 ? 4 : 2;             // chunks * (k - 1) <= 3 scratch slots behind the list
+#else
         const int k = chunks * 4 <= NW && chunks <= 2 ? 4 : 2;
+#endif
         const int chunk = wave / k, slice = wave - chunk * k;
         // scratch slot q = chunk * (k - 1) + slice - 1 (at most 6 of 64 doubles): three behind the first 256
         // entries of each queue (chunks <= 4, so neither queue holds more than 256 entries in this stage;
         // ROWS >= 16 makes a queue 2 KB; the host keeps tile_words even, so the doubles are 8-byte aligned)
         double* const scr0 = (double*)(queue + 256);
+#ifndef HC_PLAIN_QUEUES
+        double* const scr1 = scr0;                                // never used: at most three slots in this build
+#else
         double* const scr1 = (double*)(queue + TILE_WIN + 256);
+#endif
         const int i = chunk * 64 + lane;
         const bool active = chunk < chunks && i < n;
         const int pos = active ? qin[i] : qin[0];
@@ -882,6 +973,9 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           part += stages[s].bsum;                                 // stage_partial_kinds sums [v < thr] * (left - right) only
           const bool ok = !(part < (double)sthr);
           const bool surv = active && ok;
+#ifndef HC_PLAIN_QUEUES
+          if (surv) HC_APPEND(pos, base, sh_out);
+#else
           const unsigned long long sm = __ballot(surv);
           if (sm) {
             int off = 0;
@@ -889,6 +983,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             off = __builtin_amdgcn_readfirstlane(off);
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
+#endif
           if (A.taps && active && !ok) A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
         }
       } else {
@@ -900,6 +995,9 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
           const bool ok = eval_stage<TREE>(tile, base, vnf_t[pos], s, stages, kinds, nodes, trees, A.leaves);
           const bool surv = active && ok;
+#ifndef HC_PLAIN_QUEUES
+          if (surv) HC_APPEND(pos, base, sh_out);
+#else
           const unsigned long long sm = __ballot(surv);
           if (sm) {
             int off = 0;
@@ -907,6 +1005,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             off = __builtin_amdgcn_readfirstlane(off);
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
+#endif
           if (A.taps && active && !ok) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
         }
         PH_MARK(3);
@@ -915,6 +1014,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       __syncthreads();
       PH_MARK(2);
     }
+#ifdef HC_PLAIN_QUEUES
     if (s == A.nstages) {                                       // the last written queue holds the accepted windows
       const int t = s - row_stages;
       const int n = cnt[t % 3];
@@ -929,6 +1029,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
       }
     }
+#endif
     PH_MARK(6);
   }
 #ifdef HC_PHASE
