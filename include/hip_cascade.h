@@ -90,6 +90,34 @@ HC_API int hc_detect_multiscale_image(hc_cascade* c, const uint8_t* image, int r
 HC_API int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int channels, size_t step_bytes,
                                uint8_t* gray, size_t gray_step_bytes);
 
+/* ---- legacy mode: OpenCV 2.4.x semantics of the same call ("T2") -------------------------
+ * The reference was written against OpenCV 2.4 (src/tracker/associator.cc:3 includes opencv2/nonfree, removed in 3.0) and
+ * passes CASCADE_SCALE_IMAGE (src/tracker/detector.cc:30), which only that generation honours.  A 2.4 build and a >= 4
+ * build return different rectangles for the same frame; everything else in this header follows >= 4, and this
+ * entry point is the explicit switch to the older behaviour: cvHaarDetectObjectsForROC, scale-image branch, scalar C
+ * path -- f64 scale ladder, cvResize(CV_INTER_LINEAR), f64 variance without the low-variance gate, no x-skip, the last
+ * row / column of window origins not scanned, area-normalised rect weights, stage bias 0.0001f, and the cascade file's
+ * STAGE TREE (parent / next; data/haarcascade_frontalface_alt_tree.xml:1303-1304) instead of a linear chain.
+ * `flags` must contain CASCADE_SCALE_IMAGE (2), as the reference's call does; minNeighbors 0 returns the raw candidates.
+ * Synchronous, host in / host out, not tuned.  Parity unpinned, like the rest.
+ * _taps: also returns, per scanned position (levels of hc_plan_query_cv24 concatenated, [gy][gx]), the number of stages
+ * passed along the window's path through the stage tree, | 64 when the window was accepted. */
+HC_API int hc_detect_multiscale_cv24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes,
+                                     double scale_factor, int min_neighbors, int flags,
+                                     int min_w, int min_h, int max_w, int max_h,
+                                     hc_rect* out, int out_capacity, int* out_count);
+HC_API int hc_detect_multiscale_cv24_taps(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes,
+                                          double scale_factor, int min_neighbors, int flags,
+                                          int min_w, int min_h, int max_w, int max_h,
+                                          hc_rect* out, int out_capacity, int* out_count,
+                                          int8_t* taps, size_t taps_capacity);
+/* levels of that call (pure host): factors[i] (f64 scale) and geometry[7*i ..] = w, h, ystep, nx, ny, win_w, win_h */
+HC_API int hc_plan_query_cv24(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h,
+                              int max_w, int max_h, double* factors, int32_t* geometry, int cap, int* nlevels);
+/* cvResize(src, dst, CV_INTER_LINEAR) of 2.4 for 8UC1 on the device (test tap of the legacy mode's first step) */
+HC_API int hc_resize_linear_cv24(const uint8_t* src, int rows, int cols, size_t step_bytes,
+                                 uint8_t* dst, int drows, int dcols);
+
 /* ---- page-locked host memory for the frame pool of the throughput path ------------------ */
 HC_API int  hc_host_alloc(size_t bytes, void** out);       /* hipHostMalloc; free with hc_host_free */
 HC_API void hc_host_free(void* p);

@@ -826,6 +826,244 @@ int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t
   return 0;
 }
 
+}  // extern "C"
+
+// ================================================================== T2: OpenCV 2.4.x legacy semantics
+// cvHaarDetectObjectsForROC with CV_HAAR_SCALE_IMAGE -- the generation the reference literally compiles against
+// (src/tracker/associator.cc:3 includes opencv2/nonfree, removed in 3.0) and the branch its flag selects
+// (src/tracker/detector.cc:30).  Restated from memory of modules/objdetect/src/haar.cpp and modules/imgproc/src/
+// imgwarp.cpp of 2.4.x; the SCALAR C path is the definition (2.4's AVX build evaluates stumps in f32 and differs).
+// [UPSTREAM-RECALL, parity unpinned]  Rules, tagged B.n:
+//  B.1 factor stays f64: winSize = cvRound(win*factor), sz = cvRound(W/factor) (f64 division); loop ends when
+//      sz - win + 1 <= 0 in either axis or winSize > maxSize; levels with winSize < minSize are skipped.
+//  B.2 level image = cvResize(img, CV_INTER_LINEAR): f32 source coordinate (float)((d+0.5)*scale-0.5), 11-bit
+//      coefficients (cvRound(c*2048) as short), horizontal pass in int, vertical
+//      ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; exact factor 2 in both axes -> (a+b+c+d+2)>>2.
+//  B.3 sum int32, sqsum f64 (exact integers: window sums of squares < 2^32 are taken modulo 2^32 here).
+//  B.4 ystep = factor > 2 ? 1 : 2 (strict); scanned positions x < sz.w - win_w, y < sz.h - win_h (the last
+//      row / column of valid origins is NOT scanned); no x-skip; no low-variance gate.
+//  B.5 per window: mean = S(equRect) * inv_area, var = SQ(equRect) * inv_area - mean^2 (f64), equRect = window
+//      shrunk by 1; vnf = var >= 0 ? sqrt(var) : 1.
+//  B.6 hidden feature weights: w_k = (float)(w_k_xml * inv_area) for k >= 1, w_0 = (float)(-sum_k>=1(w_k*area_k)/area_0).
+//  B.7 node: t = thr(f32->f64) * vnf; sum = (f32)(S(r0) * w0) -> f64, += (f32)(S(r1) * w1), [+= r2]; branch / leaf by sum < t;
+//      stage sum f64 of f32 leaves in order; stage threshold = (float)thr_xml - 0.0001f (f32 arithmetic); fail iff sum < thr.
+//  B.8 stage TREE honoured (parent / next from the XML, child = first stage naming this one as parent): pass -> child,
+//      fail -> next sibling of the nearest ancestor-or-self that has one, none -> reject; no child -> accept.
+//  B.9 Rect(cvRound(x*factor), cvRound(y*factor), winSize) in f64; groupRectangles(max(minNeighbors,1), 0.2) unless
+//      minNeighbors == 0 (raw candidates returned).
+namespace {
+
+// B.2: one axis of cv::resize(INTER_LINEAR) for 8-bit images, as resizeGeneric_ sets it up
+struct LinTab24 { std::vector<int> ofs; std::vector<short> a0, a1; };
+LinTab24 linear_table24(int ssize, int dsize) {
+  LinTab24 t;
+  t.ofs.resize(dsize); t.a0.resize(dsize); t.a1.resize(dsize);
+  const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+  for (int d = 0; d < dsize; d++) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int sidx = (int)std::floor(f);
+    f -= sidx;
+    if (sidx < 0) { f = 0; sidx = 0; }
+    if (sidx >= ssize - 1) { f = 0; sidx = ssize - 1; }
+    t.ofs[d] = sidx;
+    const float c0 = 1.f - f, c1 = f;
+    t.a0[d] = (short)cv_round(c0 * 2048.f);          // saturate_cast<short>(c * INTER_RESIZE_COEF_SCALE)
+    t.a1[d] = (short)cv_round(c1 * 2048.f);
+  }
+  return t;
+}
+
+void resize_linear_cv24(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst, int drows, int dcols) {
+  if (drows == rows && dcols == cols) { for (int y = 0; y < rows; y++) memcpy(dst + (size_t)y * cols, src + (size_t)y * step, cols); return; }
+  if (rows == 2 * drows && cols == 2 * dcols) {      // INTER_LINEAR at exactly 1/2 is routed to the area kernel
+    for (int y = 0; y < drows; y++)
+      for (int x = 0; x < dcols; x++) {
+        const uint8_t* p = src + (size_t)(2 * y) * step + 2 * x;
+        dst[(size_t)y * dcols + x] = (uint8_t)((p[0] + p[1] + p[step] + p[step + 1] + 2) >> 2);
+      }
+    return;
+  }
+  const LinTab24 tx = linear_table24(cols, dcols), ty = linear_table24(rows, drows);
+  std::vector<int> h0(dcols), h1(dcols);
+  for (int y = 0; y < drows; y++) {
+    const int sy = ty.ofs[y], sy1 = std::min(sy + 1, rows - 1);
+    const uint8_t *r0 = src + (size_t)sy * step, *r1 = src + (size_t)sy1 * step;
+    for (int x = 0; x < dcols; x++) {
+      const int sx = tx.ofs[x], sx1 = std::min(sx + 1, cols - 1);
+      h0[x] = r0[sx] * tx.a0[x] + r0[sx1] * tx.a1[x];
+      h1[x] = r1[sx] * tx.a0[x] + r1[sx1] * tx.a1[x];
+    }
+    const int b0 = ty.a0[y], b1 = ty.a1[y];
+    for (int x = 0; x < dcols; x++)
+      dst[(size_t)y * dcols + x] = (uint8_t)((((b0 * (h0[x] >> 4)) >> 16) + ((b1 * (h1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+struct Cv24Level { double factor; int w, h, ystep, nx, ny, win_w, win_h; };
+
+void cv24_plan(const orc_cascade* c, int rows, int cols, double sf, int min_w, int min_h, int max_w, int max_h,
+               std::vector<Cv24Level>& out) {
+  out.clear();
+  if (max_w == 0 || max_h == 0) { max_w = cols; max_h = rows; }
+  for (double factor = 1;; factor *= sf) {                                 // B.1
+    const int ww = cv_round(c->win_w * factor), wh = cv_round(c->win_h * factor);
+    const int w = cv_round(cols / factor), h = cv_round(rows / factor);
+    const int s1w = w - c->win_w + 1, s1h = h - c->win_h + 1;
+    if (s1w <= 0 || s1h <= 0) break;
+    if (ww > max_w || wh > max_h) break;
+    if (ww < min_w || wh < min_h) continue;
+    Cv24Level L{factor, w, h, factor > 2 ? 1 : 2, 0, 0, ww, wh};          // B.4
+    const int lim_x = w - c->win_w, lim_y = h - c->win_h;                  // exclusive
+    L.nx = (lim_x + L.ystep - 1) / L.ystep;
+    L.ny = (lim_y + L.ystep - 1) / L.ystep;
+    out.push_back(L);
+  }
+}
+
+// hidden cascade of icvCreateHidHaarClassifierCascade + cvSetImagesForHaarClassifierCascade(scale 1)
+struct Cv24Hid {
+  std::vector<float> w;            // 3 per node (B.6)
+  std::vector<float> stage_thr;    // B.7
+  std::vector<int> child;          // B.8
+  double inv_area;
+};
+
+Cv24Hid cv24_hidden(const orc_cascade* c) {
+  Cv24Hid H;
+  H.inv_area = 1. / ((double)(c->win_w - 2) * (c->win_h - 2));
+  H.w.resize(c->nodes.size() * 3);
+  for (size_t i = 0; i < c->nodes.size(); i++) {
+    const Feature& F = c->feats[c->nodes[i].feat];
+    double sum0 = 0, area0 = 0;
+    for (int k = 0; k < 3; k++) {
+      if (k > 0 && F.w[k] == 0.f) { H.w[i * 3 + k] = 0.f; continue; }     // absent third rect
+      H.w[i * 3 + k] = (float)(F.w[k] * H.inv_area);
+      if (k == 0) area0 = F.r[k][2] * F.r[k][3];
+      else sum0 += H.w[i * 3 + k] * F.r[k][2] * F.r[k][3];
+    }
+    H.w[i * 3] = (float)(-sum0 / area0);
+  }
+  const float bias = 0.0001f;
+  for (const Stage& s : c->stages) H.stage_thr.push_back((float)s.thr_raw - bias);
+  H.child.assign(c->stages.size(), -1);
+  for (size_t i = 0; i < c->stages.size(); i++) {
+    const int p = c->stages[i].parent;
+    if (p >= 0 && p < (int)c->stages.size() && H.child[p] < 0) H.child[p] = (int)i;
+  }
+  return H;
+}
+
+inline int box(const int32_t* I, int p, int x, int y, const int r[4]) {
+  const int32_t* a = I + (size_t)(y + r[1]) * p + x + r[0];
+  return a[0] - a[r[2]] - a[(size_t)r[3] * p] + a[(size_t)r[3] * p + r[2]];
+}
+
+// one stage at one window: B.7
+inline bool cv24_stage(const orc_cascade* c, const Cv24Hid& H, int si, const int32_t* S, int p, int x, int y, double vnf) {
+  const Stage& st = c->stages[si];
+  double stage_sum = 0.0;
+  for (int t = 0; t < st.ntrees; t++) {
+    const Tree& T = c->trees[st.first_tree + t];
+    int idx = 0;
+    do {
+      const int ni = T.first_node + idx;
+      const Node& N = c->nodes[ni];
+      const Feature& F = c->feats[N.feat];
+      const double thr = (double)N.thr * vnf;
+      double sum = (double)((float)box(S, p, x, y, F.r[0]) * H.w[ni * 3]);
+      sum += (double)((float)box(S, p, x, y, F.r[1]) * H.w[ni * 3 + 1]);
+      if (F.w[2] != 0.f) sum += (double)((float)box(S, p, x, y, F.r[2]) * H.w[ni * 3 + 2]);
+      idx = sum < thr ? N.left : N.right;
+    } while (idx > 0);
+    stage_sum += (double)c->leaves[T.first_leaf - idx];
+  }
+  return !(stage_sum < (double)H.stage_thr[si]);
+}
+
+}  // namespace
+
+extern "C" int orc_resize_linear_cv24(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst, int drows, int dcols) {
+  if (rows <= 0 || cols <= 0 || drows <= 0 || dcols <= 0) return -2;
+  resize_linear_cv24(src, rows, cols, step, dst, drows, dcols);
+  return 0;
+}
+
+extern "C" int orc_plan_cv24(const orc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w, int max_h,
+                             double* factors, int32_t* geom, int cap, int* nlevels) {
+  std::vector<Cv24Level> L;
+  cv24_plan(c, rows, cols, scale_factor, min_w, min_h, max_w, max_h, L);
+  if ((int)L.size() > cap) return -3;
+  for (size_t i = 0; i < L.size(); i++) {
+    factors[i] = L[i].factor;
+    int32_t* g = geom + 7 * i;
+    g[0] = L[i].w; g[1] = L[i].h; g[2] = L[i].ystep; g[3] = L[i].nx; g[4] = L[i].ny; g[5] = L[i].win_w; g[6] = L[i].win_h;
+  }
+  *nlevels = (int)L.size();
+  return 0;
+}
+
+// taps: int8 per scanned position, levels concatenated, [gy][gx] with nx x ny of orc_plan_cv24: number of stages PASSED along
+// the path the window took through the stage tree (for a linear cascade: stages passed before the first failure; an accepted
+// window counts every stage on its path), accepted windows additionally carry bit 6 (value | 64).
+extern "C" int orc_detect_cv24(const orc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step, double scale_factor,
+                               int min_neighbors, int min_w, int min_h, int max_w, int max_h, orc_rect* out, int cap, int* out_count,
+                               orc_rect* raw, int raw_cap, int* raw_count, int8_t* taps, size_t taps_cap) {
+  if (!c || !gray || !out_count || !(scale_factor > 1.0)) return -2;
+  std::vector<Cv24Level> levels;
+  cv24_plan(c, rows, cols, scale_factor, min_w, min_h, max_w, max_h, levels);
+  const Cv24Hid H = cv24_hidden(c);
+  std::vector<orc_rect> cands;
+  std::vector<uint8_t> img;
+  std::vector<int32_t> S, Q;
+  size_t tap_at = 0;
+  const int eq_w = c->win_w - 2, eq_h = c->win_h - 2;
+  for (const Cv24Level& L : levels) {
+    img.resize((size_t)L.w * L.h);
+    resize_linear_cv24(gray, rows, cols, step, img.data(), L.h, L.w);          // B.2
+    S.resize((size_t)(L.w + 1) * (L.h + 1)); Q.resize(S.size());
+    integral_32s(img.data(), L.h, L.w, L.w, S.data(), Q.data());               // B.3
+    const int p = L.w + 1;
+    if (taps && tap_at + (size_t)L.nx * L.ny > taps_cap) return -3;
+    for (int gy = 0; gy < L.ny; gy++)
+      for (int gx = 0; gx < L.nx; gx++) {
+        const int x = gx * L.ystep, y = gy * L.ystep;
+        const int eq[4] = {1, 1, eq_w, eq_h};
+        const double mean = box(S.data(), p, x, y, eq) * H.inv_area;           // B.5
+        const double sq = (double)(uint32_t)box(Q.data(), p, x, y, eq);
+        double vnf = sq * H.inv_area - mean * mean;
+        vnf = vnf >= 0. ? std::sqrt(vnf) : 1.;
+        int si = 0, passed = 0;
+        bool accept = false;
+        for (;;) {                                                              // B.8
+          if (cv24_stage(c, H, si, S.data(), p, x, y, vnf)) {
+            ++passed;
+            if (H.child[si] < 0) { accept = true; break; }
+            si = H.child[si];
+          } else {
+            while (si >= 0 && c->stages[si].next < 0) si = c->stages[si].parent;
+            if (si < 0) break;
+            si = c->stages[si].next;
+          }
+        }
+        if (taps) taps[tap_at + (size_t)gy * L.nx + gx] = (int8_t)(std::min(passed, 63) | (accept ? 64 : 0));
+        if (accept) cands.push_back(orc_rect{cv_round(x * L.factor), cv_round(y * L.factor), L.win_w, L.win_h});   // B.9
+      }
+    tap_at += (size_t)L.nx * L.ny;
+  }
+  if (raw_count) *raw_count = (int)cands.size();
+  if (raw) {
+    if ((int)cands.size() > raw_cap) return -3;
+    for (size_t i = 0; i < cands.size(); i++) raw[i] = cands[i];
+  }
+  if (min_neighbors != 0) group_rects(cands, std::max(min_neighbors, 1), 0.2);
+  if ((int)cands.size() > cap) return -3;
+  for (size_t i = 0; i < cands.size(); i++) out[i] = cands[i];
+  *out_count = (int)cands.size();
+  return 0;
+}
+
+extern "C" {
+
 int orc_eval_patch(const orc_cascade* c, const uint8_t* patch, double* margins) {
   std::vector<int32_t> sum((size_t)(c->win_w + 1) * (c->win_h + 1)), sq(sum.size());
   integral_32s(patch, c->win_h, c->win_w, c->win_w, sum.data(), sq.data());

@@ -119,6 +119,18 @@ int orc_resize_area(const uint8_t* src, int rows, int cols, int channels, size_t
  * detectMultiScale applies to a multi-channel image and FaceDetector::detectFaces at detector.cc:20. */
 int orc_bgr2gray(const uint8_t* src, int rows, int cols, int channels, size_t step, uint8_t* gray);
 
+/* ---- T2: OpenCV 2.4.x legacy semantics (rules B.1-B.9 at the top of that section in haar_oracle.cpp):
+ * cvHaarDetectObjectsForROC with CV_HAAR_SCALE_IMAGE, scalar C path, stage tree honoured (alt_tree).  Unpinned. */
+int orc_resize_linear_cv24(const uint8_t* src, int rows, int cols, size_t step, uint8_t* dst, int drows, int dcols);
+/* levels of the call: factors[i] (f64) and geom[7*i ..] = w, h, ystep, nx, ny, win_w, win_h */
+int orc_plan_cv24(const orc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w, int max_h,
+                  double* factors, int32_t* geom, int cap, int* nlevels);
+/* taps: int8 per scanned position (levels concatenated, [gy][gx]): stages passed along the window's path through the
+ * stage tree, | 64 when accepted.  min_neighbors 0 returns the raw candidates ungrouped, as upstream does. */
+int orc_detect_cv24(const orc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step, double scale_factor,
+                    int min_neighbors, int min_w, int min_h, int max_w, int max_h, orc_rect* out, int cap, int* out_count,
+                    orc_rect* raw, int raw_cap, int* raw_count, int8_t* taps, size_t taps_cap);
+
 /* Evaluate one window-sized patch (win_h x win_w, tight) at scale 1: returns number of
  * stages passed (nstages = accepted), -1 if not evaluable. margins (optional, nstages
  * doubles) receive stage_sum - stage_threshold for every stage evaluated regardless of

@@ -40,6 +40,8 @@ def load_hcc(path):
     # A.2: (float)t - 1e-5f evaluated in f32
     c.stage_thr = (st["thr"].astype(F32) - F32(1e-5)).astype(F32)
     c.stage_ntrees = st["nt"].copy()
+    c.stage_parent = st["par"].copy()
+    c.stage_next = st["nxt"].copy()
     c.tree_nnodes = np.frombuffer(b, "<i4", ntr, p).copy()
     p += ntr * 4
     nd = np.frombuffer(b, dtype=np.dtype([("r", "i1", (3, 4)), ("w", "<f4", 3), ("thr", "<f4"), ("left", "<i4"),
@@ -414,3 +416,136 @@ def resize_area(img, drows, dcols):
             out[dy] = np.rint(acc).astype(np.int64)
     out = np.clip(out, 0, 255).astype(np.uint8)
     return out[:, :, 0] if np.asarray(img).ndim == 2 else out
+
+
+# ----------------------------------------------------------------------------- T2: OpenCV 2.4.x legacy semantics
+# Second restatement of oracle/haar_oracle.cpp's orc_detect_cv24 (rules B.1-B.9 there), array-at-a-time: every window
+# of a level is evaluated together, breadth-first over the stage tree (all windows that currently sit at stage s
+# take stage s in one go), instead of the C++ oracle's window-at-a-time walk.
+def plan_cv24(c, rows, cols, sf=1.1, min_size=(0, 0), max_size=(0, 0)):
+    max_w, max_h = max_size if (max_size[0] and max_size[1]) else (cols, rows)
+    levels, factor = [], 1.0
+    while True:
+        ww, wh = cv_round(c.win_w * factor), cv_round(c.win_h * factor)
+        w, h = cv_round(cols / factor), cv_round(rows / factor)
+        if w - c.win_w + 1 <= 0 or h - c.win_h + 1 <= 0 or ww > max_w or wh > max_h:
+            break
+        if ww >= min_size[0] and wh >= min_size[1]:
+            ystep = 1 if factor > 2 else 2
+            levels.append(dict(factor=factor, w=w, h=h, ystep=ystep, nx=-(-(w - c.win_w) // ystep), ny=-(-(h - c.win_h) // ystep),
+                               win_w=ww, win_h=wh))
+        factor *= sf
+    return levels
+
+
+def _lin24(ssize, dsize):
+    d = np.arange(dsize, dtype=F64)
+    scale = F64(1.0) / (F64(dsize) / F64(ssize))
+    f = ((d + 0.5) * scale - 0.5).astype(F32)
+    sidx = np.floor(f).astype(np.int64)
+    f = (f - sidx.astype(F32)).astype(F32)
+    lo, hi = sidx < 0, sidx >= ssize - 1
+    f[lo | hi] = 0
+    sidx = np.clip(sidx, 0, ssize - 1)
+    a1 = np.rint(f * F32(2048)).astype(np.int64)
+    a0 = np.rint((F32(1) - f) * F32(2048)).astype(np.int64)
+    return sidx, np.minimum(sidx + 1, ssize - 1), a0, a1
+
+
+def resize_linear_cv24(img, drows, dcols):
+    a = np.asarray(img).astype(np.int64)
+    rows, cols = a.shape
+    if (rows, cols) == (drows, dcols):
+        return np.asarray(img).copy()
+    if rows == 2 * drows and cols == 2 * dcols:
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    sx, sx1, ax0, ax1 = _lin24(cols, dcols)
+    sy, sy1, ay0, ay1 = _lin24(rows, drows)
+    hor = a[:, sx] * ax0[None, :] + a[:, sx1] * ax1[None, :]                 # every source row, destination columns
+    v = ((ay0[:, None] * (hor[sy] >> 4)) >> 16) + ((ay1[:, None] * (hor[sy1] >> 4)) >> 16)
+    return ((v + 2) >> 2).astype(np.uint8)
+
+
+def detect_cv24(c, gray, sf=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), want_taps=False):
+    rows, cols = gray.shape
+    inv_area = F64(1.0) / F64((c.win_w - 2) * (c.win_h - 2))
+    # hidden weights (B.6) and stage thresholds / children (B.7, B.8)
+    rects = c.rects.astype(np.int64)
+    area = rects[:, :, 2] * rects[:, :, 3]
+    w = (c.weights.astype(F64) * inv_area).astype(F32)
+    w[c.weights == 0] = 0
+    sum0 = (w[:, 1].astype(F64) * area[:, 1]) + 0.0
+    three = c.weights[:, 2] != 0
+    sum0 = np.where(three, sum0 + w[:, 2].astype(F64) * area[:, 2], sum0)
+    w[:, 0] = (-sum0 / area[:, 0]).astype(F32)
+    stage_thr = (c.stage_thr_raw.astype(F32) - F32(0.0001)).astype(F32)
+    nst = len(stage_thr)
+    child = np.full(nst, -1)
+    for i in range(nst):
+        pnt = int(c.stage_parent[i])
+        if 0 <= pnt < nst and child[pnt] < 0:
+            child[pnt] = i
+    tree_first = np.concatenate([[0], np.cumsum(c.stage_ntrees)])
+    node_first = np.concatenate([[0], np.cumsum(c.tree_nnodes)])
+    leaf_first = np.concatenate([[0], np.cumsum(c.tree_nnodes + 1)])
+    cands, taps = [], []
+    for L in plan_cv24(c, rows, cols, sf, min_size, max_size):
+        img = resize_linear_cv24(gray, L["h"], L["w"])
+        S = np.zeros((L["h"] + 1, L["w"] + 1), np.int64)
+        S[1:, 1:] = img.astype(np.int64).cumsum(0).cumsum(1)
+        Q = np.zeros_like(S)
+        Q[1:, 1:] = (img.astype(np.int64) ** 2).cumsum(0).cumsum(1)
+        gy, gx = np.mgrid[0:L["ny"], 0:L["nx"]]
+        y, x = (gy * L["ystep"]).ravel(), (gx * L["ystep"]).ravel()
+
+        def box(I, r, idx):
+            yy, xx = y[idx] + r[1], x[idx] + r[0]
+            return I[yy, xx] - I[yy, xx + r[2]] - I[yy + r[3], xx] + I[yy + r[3], xx + r[2]]
+        eq = (1, 1, c.win_w - 2, c.win_h - 2)
+        allw = np.arange(len(x))
+        mean = box(S, eq, allw).astype(F64) * inv_area
+        var = box(Q, eq, allw).astype(F64) * inv_area - mean * mean
+        vnf = np.where(var >= 0, np.sqrt(np.maximum(var, 0)), 1.0)
+        at = np.zeros(len(x), np.int64)            # stage each window sits at; -1 rejected, -2 accepted
+        passed = np.zeros(len(x), np.int64)
+        while (at >= 0).any():
+            for s in np.unique(at[at >= 0]):
+                idx = np.nonzero(at == s)[0]
+                ssum = np.zeros(len(idx), F64)
+                for t in range(tree_first[s], tree_first[s + 1]):
+                    node = np.zeros(len(idx), np.int64)
+                    leaf = np.zeros(len(idx), F64)
+                    live = np.ones(len(idx), bool)
+                    while live.any():
+                        for k in np.unique(node[live]):
+                            sel = live & (node == k)
+                            ni = node_first[t] + k
+                            thr = F64(c.node_thr[ni]) * vnf[idx[sel]]
+                            fs = (box(S, rects[ni, 0], idx[sel]).astype(F32) * w[ni, 0]).astype(F64)
+                            fs = fs + (box(S, rects[ni, 1], idx[sel]).astype(F32) * w[ni, 1]).astype(F64)
+                            if c.weights[ni, 2] != 0:
+                                fs = fs + (box(S, rects[ni, 2], idx[sel]).astype(F32) * w[ni, 2]).astype(F64)
+                            go = np.where(fs < thr, c.node_left[ni], c.node_right[ni])
+                            sub = np.nonzero(sel)[0]
+                            done = go <= 0
+                            leaf[sub[done]] = c.leaves[leaf_first[t] - go[done]].astype(F64)
+                            live[sub[done]] = False
+                            node[sub[~done]] = go[~done]
+                    ssum = ssum + leaf
+                ok = ~(ssum < F64(stage_thr[s]))
+                passed[idx[ok]] += 1
+                nxt = np.empty(len(idx), np.int64)
+                nxt[ok] = child[s] if child[s] >= 0 else -2
+                # failure: next sibling of the nearest ancestor-or-self that has one
+                f = s
+                while f >= 0 and c.stage_next[f] < 0:
+                    f = int(c.stage_parent[f])
+                nxt[~ok] = int(c.stage_next[f]) if f >= 0 else -1
+                at[idx] = nxt
+        acc = at == -2
+        taps.append((np.minimum(passed, 63) | np.where(acc, 64, 0)).astype(np.int8).reshape(L["ny"], L["nx"]))
+        for i in np.nonzero(acc)[0]:
+            cands.append((cv_round(x[i] * L["factor"]), cv_round(y[i] * L["factor"]), L["win_w"], L["win_h"]))
+    raw = np.array(cands, np.int32).reshape(-1, 4)
+    grouped = group_rectangles(raw, max(min_neighbors, 1)) if min_neighbors != 0 else raw
+    return (grouped, raw, taps) if want_taps else (grouped, raw)

@@ -59,6 +59,12 @@ def lib():
         L.orc_detect_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_int] * 6 + \
                                      [C.c_void_p]
         L.orc_eval_patch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_resize_linear_cv24.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
+        L.orc_plan_cv24.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_int,
+                                                                                              C.POINTER(C.c_int)]
+        L.orc_detect_cv24.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double] + [C.c_int] * 5 + \
+                                     [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                                      C.c_void_p, C.c_size_t]
         L.orc_bgr2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p]
         L.orc_resize_area.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]
         L.orc_detect_faces.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
@@ -139,6 +145,42 @@ class OracleCascade:
             res.append(per)
         return res
 
+    def plan_cv24(self, rows, cols, sf=1.1, min_size=(0, 0), max_size=(0, 0)):
+        """levels of the OpenCV-2.4 (T2) call: list of dicts factor, w, h, ystep, nx, ny, win_w, win_h"""
+        fac = np.zeros(256, np.float64)
+        geo = np.zeros((256, 7), np.int32)
+        n = C.c_int()
+        rc = lib().orc_plan_cv24(self._h, rows, cols, sf, min_size[0], min_size[1], max_size[0], max_size[1], fac.ctypes.data,
+                                 geo.ctypes.data, 256, C.byref(n))
+        if rc:
+            raise RuntimeError("orc_plan_cv24 %d" % rc)
+        keys = "w h ystep nx ny win_w win_h".split()
+        return [dict(factor=float(fac[i]), **{k: int(v) for k, v in zip(keys, geo[i])}) for i in range(n.value)]
+
+    def detect_cv24(self, gray, sf=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), want_taps=False, cap=1 << 16,
+                    raw_cap=1 << 20):
+        """T2 / OpenCV 2.4.x semantics -> grouped, raw [, taps per level: stages passed | 64 if accepted]"""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        rows, cols = gray.shape
+        out = np.zeros((cap, 4), np.int32)
+        raw = np.zeros((raw_cap, 4), np.int32)
+        n, nr = C.c_int(), C.c_int()
+        levels = self.plan_cv24(rows, cols, sf, min_size, max_size)
+        taps = np.zeros(max(sum(l["nx"] * l["ny"] for l in levels), 1), np.int8)
+        rc = lib().orc_detect_cv24(self._h, gray.ctypes.data, rows, cols, gray.strides[0], sf, min_neighbors, min_size[0],
+                                   min_size[1], max_size[0], max_size[1], out.ctypes.data, cap, C.byref(n), raw.ctypes.data,
+                                   raw_cap, C.byref(nr), taps.ctypes.data if want_taps else None, taps.size)
+        if rc:
+            raise RuntimeError("orc_detect_cv24 %d" % rc)
+        res = [out[:n.value].copy(), raw[:nr.value].copy()]
+        if want_taps:
+            per, o = [], 0
+            for l in levels:
+                per.append(taps[o:o + l["nx"] * l["ny"]].reshape(l["ny"], l["nx"]))
+                o += l["nx"] * l["ny"]
+            res.append(per)
+        return res
+
     def detect_faces(self, bgr, lower=(0, 133, 77), upper=(255, 173, 127), scale=1.1, want_taps=False, cap=4096):
         """FaceDetector::detectFaces (reference src/tracker/detector.cc:10-43) -> rects [, mask, gray]"""
         bgr = np.ascontiguousarray(bgr, np.uint8)
@@ -171,6 +213,14 @@ def resize_linear_exact(img, drows, dcols):
     dst = np.zeros((drows, dcols), np.uint8)
     rc = lib().orc_resize_linear_exact(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], dst.ctypes.data,
                                        drows, dcols)
+    assert rc == 0
+    return dst
+
+
+def resize_linear_cv24(img, drows, dcols):
+    img = np.ascontiguousarray(img, np.uint8)
+    dst = np.zeros((drows, dcols), np.uint8)
+    rc = lib().orc_resize_linear_cv24(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], dst.ctypes.data, drows, dcols)
     assert rc == 0
     return dst
 

@@ -1,0 +1,83 @@
+"""GPU parity of the legacy mode ("T2"): OpenCV 2.4.x semantics of the reference's call at
+src/tracker/detector.cc:25-31 -- the generation it was built against (src/tracker/associator.cc:3) and the branch its
+CASCADE_SCALE_IMAGE flag selects -- through hc_detect_multiscale_cv24, against the CPU oracle's restatement
+(oracle/haar_oracle.cpp orc_detect_cv24, itself cross-checked against numpy in tests/test_oracle.py).
+Bit-exact: resize bytes, per-window stage taps, raw candidates in scan order, grouped boxes.  Unpinned against a real
+2.4 build, like the >= 4 semantics."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cv24_resize_bytes(pkg, oracle):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (97, 131), dtype=np.uint8)
+    for dst in [(97, 131), (60, 81), (45, 61), (33, 47), (20, 27), (7, 9)]:
+        assert np.array_equal(pkg.resize_linear_cv24(img, *dst), oracle.resize_linear_cv24(img, *dst)), dst
+    even = rng.integers(0, 256, (80, 120), dtype=np.uint8)
+    assert np.array_equal(pkg.resize_linear_cv24(even, 40, 60), oracle.resize_linear_cv24(even, 40, 60))       # exact 1/2: area kernel
+    wide = np.zeros((97, 140), np.uint8)
+    wide[:, :131] = img
+    assert np.array_equal(pkg.resize_linear_cv24(wide[:, :131], 45, 61), oracle.resize_linear_cv24(img, 45, 61))   # row step > cols
+
+
+@pytest.mark.parametrize("name", ["alt", "alt2", "default", "alt_tree"])
+def test_cv24_all_taps_small(pkg, oracle, synth, name):
+    """stumps, depth-2 trees, the 24x24 window and alt_tree's branching stage tree on planted / texture / noise frames"""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = [synth.planted(240, 320, synth.frame_seed(300), nfaces=3, min_size=40, max_size=110)[0],
+              synth.texture(150, 211, synth.frame_seed(301)), synth.noise(90, 120, synth.frame_seed(302))]
+    nraw = 0
+    for fr in frames:
+        for mn in (2, 0):
+            want, raw, wtaps = oc.detect_cv24(fr, 1.1, mn, (30, 30), (0, 0), want_taps=True)
+            got, taps = casc.detect_multiscale_cv24(fr, 1.1, mn, 2, (30, 30), (0, 0), want_taps=True)
+            assert len(taps) == len(wtaps) and casc.plan_cv24(*fr.shape, 1.1, (30, 30)) == oc.plan_cv24(*fr.shape, 1.1, (30, 30))
+            for li, (a, b) in enumerate(zip(taps, wtaps)):
+                assert np.array_equal(a, b), "%s level %d: %d taps differ" % (name, li, int((a != b).sum()))
+            assert np.array_equal(got, want), (name, mn)
+            if mn == 0:
+                assert np.array_equal(got, raw)
+                nraw += len(raw)
+    assert nraw > 0
+
+
+def test_cv24_full_size_720p_and_limits(pkg, oracle, synth):
+    """the reference's literal call (scale 1.1, minNeighbors 2, 0|CASCADE_SCALE_IMAGE, Size(30,30)) on a 1280x720 frame,
+    alt and alt_tree; other scale factors / size limits; the branch without CASCADE_SCALE_IMAGE is not restated"""
+    fr = synth.planted(720, 1280, synth.frame_seed(0))[0]
+    for name in ("alt", "alt_tree"):
+        path = oracle.cascade_path(name)
+        casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+        want, raw = oc.detect_cv24(fr, 1.1, 2, (30, 30))
+        assert np.array_equal(casc.detect_multiscale_cv24(fr, 1.1, 2, 2, (30, 30)), want) and len(want) >= 4
+        assert np.array_equal(casc.detect_multiscale_cv24(fr, 1.1, 0, 2, (30, 30), capacity=1 << 18), raw)
+    casc, oc = pkg.Cascade(oracle.cascade_path("alt2")), oracle.OracleCascade(oracle.cascade_path("alt2"))
+    small = synth.planted(240, 320, synth.frame_seed(21), nfaces=4, min_size=40, max_size=110)[0]
+    for sf, mn, mins, maxs in [(1.2, 3, (0, 0), (0, 0)), (1.05, 2, (40, 40), (90, 90)), (1.3, 1, (24, 24), (0, 0))]:
+        assert np.array_equal(casc.detect_multiscale_cv24(small, sf, mn, 2, mins, maxs), oc.detect_cv24(small, sf, mn, mins, maxs)[0]), (sf, mn)
+    with pytest.raises(pkg.HipCascadeError) as e:
+        casc.detect_multiscale_cv24(small, 1.1, 2, 0, (30, 30))
+    assert e.value.code == -4
+    # the two generations really differ on the same frame (different ladders, resize, grids, thresholds)
+    t4 = casc.detect_multiscale(small, 1.1, 2, 2, (30, 30))
+    t2 = casc.detect_multiscale_cv24(small, 1.1, 2, 2, (30, 30))
+    assert len(t4) > 0 and len(t2) > 0
+
+
+def test_cv24_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
+    """hip_cascade::CascadeClassifier::setLegacySemantics(true) + the reference's call"""
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "shim_demo")
+    frame, _ = synth.planted(240, 320, synth.frame_seed(0), nfaces=3, min_size=40, max_size=110)
+    f = tmp_path / "frame.u8"
+    frame.tofile(f)
+    r = subprocess.run([demo, oracle.cascade_path("alt_tree"), str(f), "240", "320", "1.1", "legacy"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
+    want, _ = oracle.OracleCascade(oracle.cascade_path("alt_tree")).detect_cv24(frame, 1.1, 2, (30, 30))
+    assert np.array_equal(got, want) and len(want) > 0

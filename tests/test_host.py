@@ -209,3 +209,18 @@ def test_box_file_through_the_c_abi(pkg, tmp_path):
     dup_ids = np.array([5, 5], np.int32)
     dofs = np.array([0, 0, 0], np.int32)
     assert pkg.lib.hc_boxes_save(str(tmp_path / "dup").encode(), 2, dup_ids.ctypes.data, dofs.ctypes.data, None) == -3
+
+
+def test_cv24_plan_matches_oracle_without_a_device(pkg, oracle):
+    """hc_plan_query_cv24 (pure host): the legacy mode's f64 ladder and scan grids equal the oracle's for several
+    geometries / scale factors / size limits and both window sizes."""
+    for name in ("alt", "default"):
+        casc, oc = pkg.Cascade(oracle.cascade_path(name)), oracle.OracleCascade(oracle.cascade_path(name))
+        for rows, cols, sf, mins, maxs in [(720, 1280, 1.1, (30, 30), (0, 0)), (360, 640, 1.1, (30, 30), (0, 0)),
+                                           (97, 131, 1.2, (0, 0), (0, 0)), (240, 320, 1.05, (40, 40), (90, 90)), (19, 40, 1.1, (0, 0), (0, 0)),
+                                           (24, 24, 1.3, (0, 0), (0, 0))]:
+            a, b = casc.plan_cv24(rows, cols, sf, mins, maxs), oc.plan_cv24(rows, cols, sf, mins, maxs)
+            assert a == b, (name, rows, cols, sf)
+    import ctypes as C
+    n = C.c_int()
+    assert pkg.lib.hc_detect_multiscale_cv24(None, None, 1, 1, 1, 1.1, 2, 2, 0, 0, 0, 0, None, 0, C.byref(n)) == -3

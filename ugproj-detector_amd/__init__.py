@@ -73,6 +73,15 @@ _SIGS = {
     "hc_boxes_save": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_boxes_load": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                 C.POINTER(C.c_int)]),
+    "hc_detect_multiscale_cv24": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_int)]),
+    "hc_detect_multiscale_cv24_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
+                                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                 C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    "hc_plan_query_cv24": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 4 +
+                           [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "hc_resize_linear_cv24": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_int]),
     "hc_context_create": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "hc_context_destroy": (None, [C.c_void_p]),
     "hc_context_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 7),
@@ -163,6 +172,38 @@ class Cascade:
         _check(lib.hc_plan_query(self._h, rows, cols, scale_factor, min_size[0], min_size[1], max_size[0],
                                  max_size[1], buf, 256, C.byref(n), C.byref(ab)))
         return [buf[i] for i in range(n.value)], ab.value
+
+    def plan_cv24(self, rows, cols, scale_factor=1.1, min_size=(0, 0), max_size=(0, 0)):
+        """levels of the legacy (OpenCV 2.4) call: list of dicts factor, w, h, ystep, nx, ny, win_w, win_h; pure host"""
+        fac = np.zeros(256, np.float64)
+        geo = np.zeros((256, 7), np.int32)
+        n = C.c_int()
+        _check(lib.hc_plan_query_cv24(self._h, rows, cols, scale_factor, min_size[0], min_size[1], max_size[0], max_size[1],
+                                      fac.ctypes.data, geo.ctypes.data, 256, C.byref(n)))
+        keys = "w h ystep nx ny win_w win_h".split()
+        return [dict(factor=float(fac[i]), **{k: int(v) for k, v in zip(keys, geo[i])}) for i in range(n.value)]
+
+    def detect_multiscale_cv24(self, gray, scale_factor=1.1, min_neighbors=3, flags=2, min_size=(0, 0), max_size=(0, 0),
+                               capacity=1 << 16, want_taps=False):
+        """legacy mode: OpenCV 2.4.x semantics (hc_detect_multiscale_cv24) -> (K,4) [, taps per level]"""
+        gray = np.asarray(gray)
+        if gray.dtype != np.uint8 or gray.ndim != 2 or gray.strides[1] != 1:
+            raise ValueError("need a 2-D uint8 image with unit column stride")
+        out = np.zeros((capacity, 4), np.int32)
+        n = C.c_int()
+        levels = self.plan_cv24(gray.shape[0], gray.shape[1], scale_factor, min_size, max_size) if want_taps else []
+        taps = np.zeros(max(sum(l["nx"] * l["ny"] for l in levels), 1), np.int8)
+        _check(lib.hc_detect_multiscale_cv24_taps(self._h, gray.ctypes.data, gray.shape[0], gray.shape[1], gray.strides[0],
+                                                  scale_factor, min_neighbors, flags, min_size[0], min_size[1], max_size[0],
+                                                  max_size[1], out.ctypes.data, capacity, C.byref(n),
+                                                  taps.ctypes.data if want_taps else None, taps.size if want_taps else 0))
+        if not want_taps:
+            return out[:n.value].copy()
+        per, o = [], 0
+        for l in levels:
+            per.append(taps[o:o + l["nx"] * l["ny"]].reshape(l["ny"], l["nx"]))
+            o += l["nx"] * l["ny"]
+        return out[:n.value].copy(), per
 
     def detect_faces(self, bgr, lower=SKIN_LOWER, upper=SKIN_UPPER, scale=1.1, capacity=4096):
         """FaceDetector::detectFaces(frame, rects) (reference src/tracker/detector.cc:10-43)"""
@@ -328,6 +369,16 @@ def configure_shared(contexts, rows, cols, scale_factor=1.1, min_neighbors=3, mi
                                            min_size[1], max_size[0], max_size[1], max_batch, cand_capacity))
     for c in contexts:
         c.rows, c.cols, c.max_batch = rows, cols, max_batch
+
+
+def resize_linear_cv24(img, drows, dcols):
+    """cvResize(CV_INTER_LINEAR) of OpenCV 2.4 on the device (hc_resize_linear_cv24)"""
+    img = np.asarray(img)
+    if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1:
+        raise ValueError("need a 2-D uint8 image with unit column stride")
+    dst = np.zeros((drows, dcols), np.uint8)
+    _check(lib.hc_resize_linear_cv24(img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], dst.ctypes.data, drows, dcols))
+    return dst
 
 
 def bgr2gray(img):

@@ -24,6 +24,7 @@
 #include "../../include/hip_cascade.h"
 #include "cascade_model.h"
 #include "group_rects.h"
+#include "hc_internal.h"
 #include "kernels.h"
 #include "scale_plan.h"
 
@@ -116,11 +117,9 @@ class WorkerPool {
   bool stop_ = false;
 };
 
-struct hc_cascade {
-  hc::Model model;
-  std::mutex mu;                 // guards default_ctx (sync API)
-  hc_context* default_ctx = nullptr;
-};
+namespace hc {
+int set_error(int code, const std::string& what) { return set_err(code, what); }   // for the other translation units
+}
 
 struct hc_context {
   const hc_cascade* casc = nullptr;

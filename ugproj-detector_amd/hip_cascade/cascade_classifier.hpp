@@ -94,6 +94,13 @@ class CascadeClassifier {
   }
   bool empty() const { return h_ == nullptr; }
 
+  // Explicit switch to the OpenCV 2.4.x evaluation the reference was written against (see
+  // hc_detect_multiscale_cv24 in include/hip_cascade.h).  Off by default: the backend follows OpenCV >= 4.  With it on,
+  // detectMultiScale needs the CASCADE_SCALE_IMAGE flag (the reference passes it, src/tracker/detector.cc:30) and a
+  // 1-channel image.
+  void setLegacySemantics(bool on) { legacy_ = on; }
+  bool legacySemantics() const { return legacy_; }
+
   void detectMultiScale(const Mat& image, std::vector<Rect>& objects, double scaleFactor = 1.1, int minNeighbors = 3,
                         int flags = 0, Size minSize = Size(), Size maxSize = Size()) {
     objects.clear();                                    // upstream clears the output first
@@ -107,10 +114,15 @@ class CascadeClassifier {
     for (;;) {
       objects.resize(cap);
       int n = 0;
-      const int rc = hc_detect_multiscale_image(h_, mat_data(image), mat_rows(image), mat_cols(image), ch, mat_step(image),
-                                                scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
-                                                maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
-                                                cap, &n);
+      const int rc = legacy_ && ch == 1
+                         ? hc_detect_multiscale_cv24(h_, mat_data(image), mat_rows(image), mat_cols(image), mat_step(image),
+                                                     scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
+                                                     maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
+                                                     cap, &n)
+                         : hc_detect_multiscale_image(h_, mat_data(image), mat_rows(image), mat_cols(image), ch, mat_step(image),
+                                                      scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
+                                                      maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
+                                                      cap, &n);
       if (rc == HC_ERR_CAPACITY && cap < (1 << 22)) { cap *= 4; continue; }
       if (rc != HC_OK) {
         objects.clear();
@@ -125,6 +137,7 @@ class CascadeClassifier {
 
  private:
   hc_cascade* h_ = nullptr;
+  bool legacy_ = false;
 };
 
 }  // namespace hip_cascade

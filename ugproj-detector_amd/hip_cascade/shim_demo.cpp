@@ -2,7 +2,8 @@
 // tracker uses cv::CascadeClassifier: load() once (src/file_io.cc:11), then
 // detectMultiScale(gray, faces, scale, 2, 0|CASCADE_SCALE_IMAGE, Size(30,30)) per frame
 // (src/tracker/detector.cc:25-31).  Input: a raw 8-bit gray frame file.
-//   shim_demo <cascade.xml|.hcc> <frame.u8> <rows> <cols> [scale=1.1]
+//   shim_demo <cascade.xml|.hcc> <frame.u8> <rows> <cols> [scale=1.1] [legacy]
+// A sixth argument "legacy" switches the classifier to the OpenCV 2.4.x evaluation (setLegacySemantics).
 // Output: one "x y w h" line per detected face; exit code 0 on success, 1 on load failure
 // (the reference's convention), 2 on a detection error.
 #include <cstdio>
@@ -47,6 +48,7 @@ int main(int argc, char** argv) {
   if (!cascade.load(argv[1])) { fprintf(stderr, "cannot load cascade %s\n", argv[1]); return 1; }
   const int rows = atoi(argv[3]), cols = atoi(argv[4]);
   const double scale = argc > 5 ? atof(argv[5]) : 1.1;
+  if (argc > 6 && !strcmp(argv[6], "legacy")) cascade.setLegacySemantics(true);
   std::vector<unsigned char> buf((size_t)rows * cols);
   FILE* f = fopen(argv[2], "rb");
   if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) { fprintf(stderr, "cannot read frame\n"); return 1; }
