@@ -53,12 +53,33 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
 
 // A.6a: variance normalisation factor of one window from the sums of its inner rect (normrect):
 // nf = area*valsq - valsum^2 (f64, exact); nf > 0: vnf = (float)(1/sqrt(nf)) kept iff area*(double)vnf < 0.1; else 0
+//
+// Upstream rounds three times: s = RN64(sqrt(nf)), r = RN64(1/s), v = RN32(r).  The correctly rounded f64 sqrt and
+// divide cost ~100 instructions per window, so v is first derived from y ~ 1/sqrt(nf) (v_rsq_f64 + two Newton
+// steps) and accepted only when that provably gives the same float: the residual e = 1 - nf*y^2, formed with an FMA,
+// bounds y's relative error by |e|/2 + 2^-53, r is within 2^-52 of the true value, and if y's mantissa bits below
+// f32 precision stay further than both errors from the rounding midpoint, no float boundary separates y from r, so
+// RN32(y) == RN32(r).  Any window failing either test (about 3 in 10^7) takes the three-rounding route literally.
+__device__ __forceinline__ float vnf_exact_slow(double nf) {
+  nf = sqrt(nf);
+  return (float)(1. / nf);
+}
+
 __device__ __forceinline__ float vnf_from_sums(int valsum, uint32_t valsq, double area) {
-  double nf = area * (double)valsq - (double)valsum * (double)valsum;
+  const double nf = area * (double)valsq - (double)valsum * (double)valsum;
   float out = 0.f;
   if (nf > 0.) {
-    nf = sqrt(nf);
-    const float v = (float)(1. / nf);
+    double y = __builtin_amdgcn_rsq(nf);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const double e = __builtin_fma(-(nf * y), y, 1.0);
+      y = __builtin_fma(y * 0.5, e, y);
+    }
+    const double e = __builtin_fma(-(nf * y), y, 1.0);
+    const unsigned int low = (unsigned int)__double2loint(y) & 0x1fffffffu;                  // 29 mantissa bits below f32 precision
+    const unsigned int dist = low > 0x10000000u ? low - 0x10000000u : 0x10000000u - low;     // ulps(f64) from the f32 rounding midpoint
+    const bool sure = fabs(e) < 0x1p-46 && dist > 160u;                                       // |dy/y| < 2^-46 = 64 ulps; r adds < 2
+    const float v = sure ? (float)y : vnf_exact_slow(nf);
     if (area * (double)v < 1e-1) out = v;
   }
   return out;
@@ -281,12 +302,30 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       const int nrows = gy_hi - gy_lo + 1;
       const double area = (double)(norm_w * norm_h);
       float* vout = vnf + (size_t)frame * grid_stride + L.grid_ofs;
-      for (int i = threadIdx.x; i < nrows * gnx; i += PI_THREADS) {
-        const int gy = gy_lo + i / gnx, gx = i - (i / gnx) * gnx;
-        const size_t p0 = (size_t)(gy * ys + 1) * pitch + gx * ys + 1, p2 = p0 + (size_t)norm_h * pitch;
-        const int valsum = (int)(S[p0] - S[p0 + norm_w] - S[p2] + S[p2 + norm_w]);
-        const uint32_t valsq = Q[p0] - Q[p0 + norm_w] - Q[p2] + Q[p2 + norm_w];
-        vout[(size_t)gy * gnx + gx] = vnf_from_sums(valsum, valsq, area);
+      // four windows per thread and trip: all 32 integral words are requested before the first is used, so a chunk
+      // pays the L2 round trip once instead of once per window (the march down the largest level is the kernel's
+      // critical path)
+      constexpr int PV = 4;
+      const int total = nrows * gnx;
+      for (int i0 = threadIdx.x; i0 < total; i0 += PV * PI_THREADS) {
+        uint32_t s00[PV], s01[PV], s10[PV], s11[PV], q00[PV], q01[PV], q10[PV], q11[PV];
+        size_t dst[PV];
+#pragma unroll
+        for (int u = 0; u < PV; u++) {
+          const int i = min(i0 + u * PI_THREADS, total - 1);     // clamped: the surplus lanes recompute the last window
+          const int gy = gy_lo + i / gnx, gx = i - (i / gnx) * gnx;
+          const size_t p0 = (size_t)(gy * ys + 1) * pitch + gx * ys + 1, p2 = p0 + (size_t)norm_h * pitch;
+          s00[u] = S[p0]; s01[u] = S[p0 + norm_w]; s10[u] = S[p2]; s11[u] = S[p2 + norm_w];
+          q00[u] = Q[p0]; q01[u] = Q[p0 + norm_w]; q10[u] = Q[p2]; q11[u] = Q[p2 + norm_w];
+          dst[u] = (size_t)gy * gnx + gx;
+        }
+#pragma unroll
+        for (int u = 0; u < PV; u++) {
+          const int valsum = (int)(s00[u] - s01[u] - s10[u] + s11[u]);
+          const uint32_t valsq = q00[u] - q01[u] - q10[u] + q11[u];
+          const float v = vnf_from_sums(valsum, valsq, area);
+          if (i0 + u * PI_THREADS < total) vout[dst[u]] = v;
+        }
       }
     }
   }
