@@ -224,3 +224,36 @@ def test_cv24_plan_matches_oracle_without_a_device(pkg, oracle):
     import ctypes as C
     n = C.c_int()
     assert pkg.lib.hc_detect_multiscale_cv24(None, None, 1, 1, 1, 1.1, 2, 2, 0, 0, 0, 0, None, 0, C.byref(n)) == -3
+
+
+def test_shim_compiles_with_opencv_spelling(tmp_path):
+    """The `HIP_CASCADE_HAVE_OPENCV` branch of the C++ shim (cv::Mat / cv::Rect / cv::Size aliases: what the reference's
+    tracker gets) had never been through a compiler: no OpenCV exists in this image.  Syntax
+    check against tests/mock_opencv (a labelled mock of the few declarations the shim touches, not OpenCV), driving
+    the reference's two calls -- src/file_io.cc:11 and src/tracker/detector.cc:25-31 -- with cv:: types."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_shim.cpp"
+    src.write_text("""
+#include <opencv2/core/core.hpp>
+#include "hip_cascade/cascade_classifier.hpp"
+#include "hip_cascade/face_detector.hpp"
+#ifndef HIP_CASCADE_HAVE_OPENCV
+#error "the OpenCV branch of the shim was not selected"
+#endif
+using namespace cv;
+int run(const Mat& gray, const Mat& frame) {
+  hip_cascade::CascadeClassifier cascade;                       // src/file_io.h:38
+  if (!cascade.load("haarcascade_frontalface_alt.xml")) return 1;   // src/file_io.cc:11
+  std::vector<Rect> facesInGray;
+  cascade.detectMultiScale(gray, facesInGray, 1.1, 2, 0 | hip_cascade::CASCADE_SCALE_IMAGE, Size(30, 30));   // detector.cc:25-31
+  hip_cascade::DetectionSection cfg;
+  hip_cascade::FaceDetector detector(cascade, cfg);             // src/tracker/face_tracker.cc:41-43
+  std::vector<Rect> rects;
+  detector.detectFaces(frame, rects);                           // src/tracker/face_tracker.cc:295
+  static_assert(std::is_same<hip_cascade::Rect, cv::Rect>::value && std::is_same<hip_cascade::Mat, cv::Mat>::value, "aliases");
+  return (int)(facesInGray.size() + rects.size());
+}
+""")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(root, "tests", "mock_opencv"),
+                        "-I", os.path.join(root, "ugproj-detector_amd"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]

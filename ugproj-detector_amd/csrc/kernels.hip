@@ -696,13 +696,23 @@ __device__ __forceinline__ void fill_tile(int32_t* tile, const uint32_t* __restr
 #else
 #define PH_MARK(k) do {} while (0)
 #endif
-template <bool TREE, int ROWS, int NW, bool SEG>   // NW wavefronts per workgroup (4 or 8); SEG: work items are band segments
+// TAPS: the per-window stage-count tap is compiled in only for the debug instantiation (tests); the production kernel
+// carries neither its branches nor its address arithmetic
+template <bool TREE, int ROWS, int NW, bool SEG, bool TAPS>   // NW wavefronts per workgroup (4 or 8); SEG: work items are band segments
 __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeArgs A) {
+  int8_t* const taps = TAPS ? A.taps : nullptr;
   constexpr int TILE_WIN = ROWS * TILE_POS;
   constexpr int NTHREADS = NW * 64;
   extern __shared__ int32_t smem[];
-  int32_t* tile = smem;
-  float* vnf_t = (float*)(smem + A.tile_words);                 // variance factor of every window of the tile
+  // The fixed-size regions come first and the integral tile (whose size depends on the window and the scan step)
+  // last: every region then starts at a compile-time constant, which the DS instructions carry in their offset field
+  // instead of each (region, lane pattern) pair occupying an address VGPR.
+  float* vnf_t = (float*)smem;                                  // variance factor of every window of the tile
+#ifndef HC_PLAIN_QUEUES
+  int32_t* tile = smem + (TILE_WIN * 8 + 136) / 4;
+#else
+  int32_t* tile = smem + (TILE_WIN * 8 + 16) / 4;
+#endif
 #ifndef HC_PLAIN_QUEUES
   // Survivor lists ordered by LDS bank.  Every corner read of a window is tile[base + off] with `off` uniform over
   // the wavefront, so which lanes of a 32-lane group collide on a bank is decided by base & 31 alone -- for every
@@ -829,14 +839,14 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
       if (((vm & fm) >> 63) & 1ull) carry &= ~(1u << j); else carry |= (1u << j);
 
       bool surv = valid && visited && evaluable && pass0;
-      if (A.taps && valid && visited && !surv)
-        A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? 0 : -1);
+      if (taps && valid && visited && !surv)
+        taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(evaluable ? 0 : -1);
       // the next stage(s) stay in row form: lanes = adjacent windows -> conflict-free LDS reads
       // and no queue traffic while most windows are still alive
       for (int s = 1; s < row_stages; s++) {
         if (!__any(surv)) break;
         const bool ok = eval_stage<TREE>(tile, base, vnf, s, stages, kinds, nodes, trees, A.leaves);
-        if (A.taps && surv && !ok) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)s;
+        if (taps && surv && !ok) taps[grid_base + (size_t)gy * nx + gx] = (int8_t)s;
         surv = surv && ok;
       }
 #ifndef HC_PLAIN_QUEUES
@@ -867,23 +877,28 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
     for (;; s++) {
       const int t = s - row_stages;
       const int sh_in = (t & 1) * 16, sh_out = 16 - sh_in;
-      const int kr = (int)((cres[lane & 31] >> sh_in) & 0xffffu);   // entries in this lane's bank column
+      // `lo` is the lane id made opaque to the optimiser: address expressions of this once-per-stage bookkeeping are
+      // then formed here instead of being hoisted out of the tile loop, where they sat in VGPRs across the stump loops
+      // (64-VGPR budget) and were spilled to scratch
+      int lo = lane;
+      asm volatile("" : "+v"(lo));
+      const int kr = (int)((cres[lo & 31] >> sh_in) & 0xffffu);   // entries in this lane's bank column
       // every wavefront derives the same layer prefix: lane j ends up with s_mine = entries in layers < j
       int n = 0, s_mine = 0, nlayers = 0;
       for (;; nlayers++) {                                          // uniform
         const unsigned int lm = (unsigned int)__ballot(kr > nlayers);   // lanes 0..31: one per bank
         if (!lm) break;
-        if (lane == nlayers) s_mine = n;
+        if (lo == nlayers) s_mine = n;
         n += __popc(lm);
       }
       if (n == 0) break;                                        // uniform
       for (int j0 = wave * 2; j0 < nlayers; j0 += NW * 2) {     // one layer per half-wavefront
         const int s0 = __builtin_amdgcn_readlane(s_mine, j0), s1 = __builtin_amdgcn_readlane(s_mine, min(j0 + 1, 63));
-        const int jl = j0 + (lane >> 5), r = lane & 31;
+        const int jl = j0 + (lo >> 5), r = lo & 31;
         const bool have = jl < kr;
         const unsigned long long hm = __ballot(have);
-        const unsigned int half = (unsigned int)(lane < 32 ? hm : (hm >> 32));
-        if (have) list[(lane < 32 ? s0 : s1) + __popc(half & ((1u << r) - 1u))] = bankm[jl * 32 + r];
+        const unsigned int half = (unsigned int)(lo < 32 ? hm : (hm >> 32));
+        if (have) list[(lo < 32 ? s0 : s1) + __popc(half & ((1u << r) - 1u))] = bankm[jl * 32 + r];
       }
       PH_MARK(4);
       __syncthreads();
@@ -897,7 +912,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             const unsigned int slot = atomicAdd(A.cand_count, 1u);
             if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
           }
-          if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
+          if (taps) taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
         }
         break;
       }
@@ -940,7 +955,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
               const unsigned int slot = atomicAdd(A.cand_count, 1u);
               if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)wy << 16) | (unsigned long long)wx;
             }
-            if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)ss;
+            if (taps) taps[grid_base + (size_t)wy * nx + wx] = (int8_t)ss;
           }
         }
         s = -1;                                                   // tile finished (uniform)
@@ -960,7 +975,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
 #else
             if (ok) qout[atomicAdd(cout, 1)] = (uint16_t)pos;
 #endif
-            else if (A.taps) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
+            else if (taps) taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
           }
         }
 #ifndef HC_PLAIN_QUEUES
@@ -988,7 +1003,9 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
 #else
         double* const scr1 = (double*)(queue + TILE_WIN + 256);
 #endif
-        const int i = chunk * 64 + lane;
+        int lc = lane;
+        asm volatile("" : "+v"(lc));                              // see `lo` above: keeps the scratch addresses out of long-lived VGPRs
+        const int i = chunk * 64 + lc;
         const bool active = chunk < chunks && i < n;
         const int pos = active ? qin[i] : qin[0];
         const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
@@ -998,7 +1015,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
                                      scount * (slice + 1) / k);
           if (slice) {
             const int q = chunk * (k - 1) + slice - 1;
-            (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lane] = part;
+            (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lc] = part;
           }
         }
         PH_MARK(3);
@@ -1007,7 +1024,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
         if (chunk < chunks && slice == 0) {
           for (int j = 1; j < k; j++) {
             const int q = chunk * (k - 1) + j - 1;
-            part += (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lane];
+            part += (q < 3 ? scr0 + q * 64 : scr1 + (q - 3) * 64)[lc];
           }
           part += stages[s].bsum;                                 // stage_partial_kinds sums [v < thr] * (left - right) only
           const bool ok = !(part < (double)sthr);
@@ -1023,7 +1040,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
 #endif
-          if (A.taps && active && !ok) A.taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
+          if (taps && active && !ok) taps[grid_base + (size_t)(gy0 + (pos >> 6)) * nx + gx0 + (pos & 63)] = (int8_t)s;
         }
       } else {
         for (int i0 = wave * 64; i0 < n; i0 += NTHREADS) {
@@ -1045,7 +1062,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
             if (surv) qout[off + __popcll(sm & lt_mask)] = (uint16_t)pos;
           }
 #endif
-          if (A.taps && active && !ok) A.taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
+          if (taps && active && !ok) taps[grid_base + (size_t)wy * nx + wx] = (int8_t)s;
         }
         PH_MARK(3);
       }
@@ -1065,7 +1082,7 @@ __global__ __launch_bounds__(NW * 64, HC_CASCADE_WAVES) void k_cascade(CascadeAr
           const unsigned int slot = atomicAdd(A.cand_count, 1u);
           if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
         }
-        if (A.taps) A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
+        if (taps) taps[grid_base + (size_t)gy * nx + gx] = (int8_t)A.nstages;
       }
     }
 #endif
@@ -1151,21 +1168,21 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
   return 0;
 }
 
-template <bool TREE, bool SEG>
+template <bool TREE, bool SEG, bool TAPS>
 static int launch_cascade_rows(hipStream_t st, int nframes, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
   const dim3 grid(nframes, args.nbands), block(nwaves * 64);
   if (nwaves == 4) {
     switch (rows) {
-      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 4, SEG>), grid, block, lds_bytes, st, args); break;
-      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 4, SEG>), grid, block, lds_bytes, st, args); break;
-      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 4, SEG>), grid, block, lds_bytes, st, args); break;
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 4, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 4, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 4, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
       default: return (int)hipErrorInvalidValue;
     }
   } else if (nwaves == 8) {
     switch (rows) {
-      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 8, SEG>), grid, block, lds_bytes, st, args); break;
-      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 8, SEG>), grid, block, lds_bytes, st, args); break;
-      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 8, SEG>), grid, block, lds_bytes, st, args); break;
+      case 8: hipLaunchKernelGGL((k_cascade<TREE, 8, 8, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
+      case 16: hipLaunchKernelGGL((k_cascade<TREE, 16, 8, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
+      case 32: hipLaunchKernelGGL((k_cascade<TREE, 32, 8, SEG, TAPS>), grid, block, lds_bytes, st, args); break;
       default: return (int)hipErrorInvalidValue;
     }
   } else {
@@ -1175,13 +1192,19 @@ static int launch_cascade_rows(hipStream_t st, int nframes, int rows, int nwaves
   return 0;
 }
 
+template <bool TREE, bool SEG>
+static int launch_cascade_taps(hipStream_t st, int nframes, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
+  return args.taps ? launch_cascade_rows<TREE, SEG, true>(st, nframes, rows, nwaves, lds_bytes, args)
+                   : launch_cascade_rows<TREE, SEG, false>(st, nframes, rows, nwaves, lds_bytes, args);
+}
+
 int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
                    const CascadeArgs& args) {
   if (args.nbands == 0 || nframes == 0) return 0;
-  const int rc_ = tree ? (segments ? launch_cascade_rows<true, true>(st, nframes, rows, nwaves, lds_bytes, args)
-                                   : launch_cascade_rows<true, false>(st, nframes, rows, nwaves, lds_bytes, args))
-                       : (segments ? launch_cascade_rows<false, true>(st, nframes, rows, nwaves, lds_bytes, args)
-                                   : launch_cascade_rows<false, false>(st, nframes, rows, nwaves, lds_bytes, args));
+  const int rc_ = tree ? (segments ? launch_cascade_taps<true, true>(st, nframes, rows, nwaves, lds_bytes, args)
+                                   : launch_cascade_taps<true, false>(st, nframes, rows, nwaves, lds_bytes, args))
+                       : (segments ? launch_cascade_taps<false, true>(st, nframes, rows, nwaves, lds_bytes, args)
+                                   : launch_cascade_taps<false, false>(st, nframes, rows, nwaves, lds_bytes, args));
 #ifdef HC_PHASE
   dump_phase(st, nwaves);
 #endif
