@@ -362,7 +362,7 @@ def test_scan_resize_any_ratio(pkg, oracle, synth, src, scan):
     assert e.value.code == -4
 
 
-def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf):
+def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf, poison_weight=False):
     """Write an HCC1 file with the first `nstages` stages of a reference cascade; optionally make
     one deep-stage leaf tiny so that the stage's f64 sum is no longer provably exact."""
     import struct
@@ -375,6 +375,10 @@ def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf):
     leaves = c.leaves[:nlf].copy()
     if poison_leaf:
         leaves[nlf - 3] = np.float32(1e-30)
+    weights = c.weights.copy()
+    if poison_weight:
+        weights[5, 1] = np.float32(2.5)          # a non-integer rect weight: the exact-integer feature build must not be used
+        weights[nnd // 2, 0] = np.float32(-2.0)  # and a first weight other than -1
     out = bytearray(b"HCC1") + struct.pack("<7i", c.win_w, c.win_h, nstages, ntr, nnd, nlf, 0)
     for i in range(nstages):
         out += struct.pack("<d3i", float(c.stage_thr_raw[i]), int(c.stage_ntrees[i]), -1, -1)
@@ -382,10 +386,10 @@ def _truncated_cascade(oracle, tmp_path, name, nstages, poison_leaf):
         out += struct.pack("<i", int(c.tree_nnodes[i]))
     for i in range(nnd):
         out += struct.pack("<12b", *[int(v) for v in c.rects[i].ravel()])
-        out += struct.pack("<3f", *[float(v) for v in c.weights[i]])
+        out += struct.pack("<3f", *[float(v) for v in weights[i]])
         out += struct.pack("<f3i", float(c.node_thr[i]), int(c.node_left[i]), int(c.node_right[i]), 0)
     out += leaves.astype("<f4").tobytes()
-    p = tmp_path / ("%s_%d_%d.hcc" % (name, nstages, int(poison_leaf)))
+    p = tmp_path / ("%s_%d_%d_%d.hcc" % (name, nstages, int(poison_leaf), int(poison_weight)))
     p.write_bytes(bytes(out))
     return str(p)
 
@@ -406,6 +410,22 @@ def test_sparse_mode_and_its_ordered_fallback(pkg, oracle, synth, tmp_path, name
     grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
     assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
     assert len(raw) > 0
+
+
+@pytest.mark.parametrize("name", ["alt", "alt2"])
+def test_non_integer_rect_weights_take_the_f32_build(pkg, oracle, synth, tmp_path, name):
+    """The production kernel forms feature values with 24-bit integer multiply-adds when the host has shown that every
+    rect weight is a small integer with w0 == -1 (true for the four reference cascades).  A cascade with a weight of
+    2.5 and a first weight of -2 must fall back to the f32 arithmetic of upstream and still match the oracle."""
+    path = _truncated_cascade(oracle, tmp_path, name, 8, False, poison_weight=True)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr, _ = synth.planted(240, 320, synth.frame_seed(4), nfaces=3, min_size=40, max_size=110)
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), 1, 1 << 15)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(fr[None])
+    grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
+    assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
 
 
 @pytest.mark.parametrize("name", ["alt2", "default"])
@@ -689,6 +709,7 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_SEG_MAX_BATCH": "0", "HC_SIDE_MAX_BATCH": "0"},  # small batches without band segments / side stream
     {"HC_SEG_TILES": "1"},
     {"HC_FUSE_VARIANCE": "0", "HC_FUSED_PREP": "1"},    # fused prep kernel, variance factors by the separate k_variance
+    {"HC_INT_WEIGHTS": "0"},                            # f32 feature arithmetic although the cascade qualifies for the integer build
     {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
     {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
 ])

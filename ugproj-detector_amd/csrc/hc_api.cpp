@@ -155,8 +155,9 @@ struct hc_context {
   // k_resize + k_integral_rows + k_integral_cols (fully parallel: 0.07 instead of 0.39 ms for ONE 720p frame).
   // -1: by batch size (fused above fused_min_batch frames), 0: never fused, 1: always fused (HC_FUSED_PREP)
   int fused_prep = -1;
+  bool allow_int_weights = true; // HC_INT_WEIGHTS=0: always the f32 feature arithmetic (A/B, debugging)
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
-  double fused_min_batch = 16;   // thresholds below are in 720p-frame equivalents: a 360p frame counts 1/4, a 1080p frame 2.25
+  double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
   int row_stages = 2;            // stages 0 and 1 in row form (conflict-free LDS reads while 88 % of the windows are alive)
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
 
@@ -178,6 +179,7 @@ struct hc_context {
   int n_seg_items[2] = {0, 0};           // bands cut into segments of seg_tiles tiles: the work list of small batches
   int seg_tiles = 1, seg_max_batch = 8;  // HC_SEG_TILES, HC_SEG_MAX_BATCH (measured: tools/exp_small_batch.sh)
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
+  bool int_weights = false;              // every node: w0 == -1, w1 / w2 integers, weighted rect sums below 2^24 (upload_model)
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;
   hc::DevTree* d_trees = nullptr;
@@ -358,6 +360,23 @@ bool stage_sum_is_exact(const hc::Model& m, const hc::ModelStage& s) {
   return 2 * units < 0x1p53L;
 }
 
+// True when upstream's f32 feature value w0*(float)S0 + w1*(float)S1 [+ w2*(float)S2] is an exact integer computation for
+// every node: w0 == -1, w1 and w2 integers, and the largest magnitude any partial value can take (rect sums are at most
+// 255 * area) stays below 2^24.  The kernel then forms it with 24-bit integer multiply-adds and converts once.
+bool weights_are_small_integers(const hc::Model& m) {
+  for (const hc::ModelNode& n : m.nodes) {
+    if (n.weight[0] != -1.f) return false;
+    double bound = 0;
+    for (int k = 0; k < 3; k++) {
+      const float w = n.weight[k];
+      if (w != std::nearbyintf(w) || std::fabs(w) > 127.f) return false;
+      bound += std::fabs((double)w) * 255.0 * n.rect[k][2] * n.rect[k][3];
+    }
+    if (!(bound < 8388608.0)) return false;     // 2^23: operands and results of v_mul_i32_i24 / the f32 mantissa
+  }
+  return true;
+}
+
 int upload_model(hc_context* c) {
   const hc::Model& m = c->casc->model;
   std::vector<hc::DevNode> nd[2];
@@ -440,6 +459,14 @@ int upload_model(hc_context* c) {
     if (all) st[i].exact = 2;
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
+  c->int_weights = c->allow_int_weights && weights_are_small_integers(m);
+  if (c->int_weights)
+    for (int g = 0; g < 2; g++)
+      for (hc::DevNode& d : nd[g])
+        for (int k = 0; k < 3; k++) {
+          const int32_t wi = (int32_t)d.w[k];
+          memcpy(&d.w[k], &wi, 4);
+        }
   int rc;
   if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;
   if ((rc = dev_upload(&c->d_nodes[1], nd[1]))) return rc;
@@ -472,6 +499,25 @@ int shared_enqueue_check(hc_context* c, int nframes) {
   return HC_OK;
 }
 
+// Which prep route a batch takes.  The fused kernel moves the fewest bytes and wins at full batches, but it is one
+// workgroup marching down each level, so its time has a floor -- the march down the LARGEST level -- that grows faster
+// than the level's area (more columns per thread, fewer workgroups per CU); the three parallel kernels have no such
+// floor.  Measured on MI355X (ms; equiv = batch size in 1280x720-frame equivalents, A = area of level 0 relative to
+// 795x447, the first level of a 720p frame): fused 0.0088 / equiv (0.0135 with the variance factors fused in), floor
+// 0.4 * A^1.45 (0.6 * ..: one 720p frame 0.39, sixteen 3840x2160 frames 18.6); parallel kernels 0.0233 / equiv, plus
+// 0.005 / equiv for k_variance where the fused kernel would have produced the factors.
+bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance) {
+  if (c->fused_prep >= 0) return c->fused_prep > 0;                         // HC_FUSED_PREP pins the route
+  const hc::Plan& P = c->plan;
+  const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
+  if (c->fused_min_batch >= 0) return equiv > c->fused_min_batch;           // HC_FUSED_MIN_BATCH: plain threshold
+  if (P.levels.empty()) return false;
+  const double A = (double)P.levels[0].w * (double)P.levels[0].h / (795.0 * 447.0);
+  const double t_fused = std::max(equiv * (fused_variance ? 0.0135 : 0.0088), (fused_variance ? 0.6 : 0.4) * std::pow(A, 1.45));
+  const double t_parallel = equiv * (fused_variance ? 0.0283 : 0.0233);
+  return t_fused < t_parallel;
+}
+
 // first-use allocations (outside the steady state: a context that has run one batch of a kind never allocates again)
 int ensure_frames(hc_context* c) {
   if (c->d_frames) return HC_OK;
@@ -494,8 +540,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   for (hc_context* f : c->followers)   // the next prep pass overwrites the integrals: the followers' scans of the last one come first
     if (f->scan_in_flight) { HIPCHK(hipStreamWaitEvent(s, f->ev_done, 0)); f->scan_in_flight = false; }
   {
-    const double equiv0 = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
-    const bool fused0 = c->fused_prep > 0 || (c->fused_prep < 0 && equiv0 > c->fused_min_batch);
+    const bool fused0 = use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty());
     int rc0;
     if (!c->leader && !P.levels.empty() && (c->taps_enabled || !fused0) && (rc0 = ensure_pyr(c))) return rc0;
     if (!P.levels.empty() && c->taps_enabled && (rc0 = ensure_taps(c))) return rc0;
@@ -515,7 +560,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       // shared prep: the leader's kernels have produced (or are producing) the integrals of this very batch
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
-    } else if (c->fused_prep > 0 || (c->fused_prep < 0 && equiv > c->fused_min_batch)) {
+    } else if (use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty())) {
       int max_w = 0;
       for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
       // the pyramid bytes only exist as a debug tap in this mode
@@ -571,6 +616,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.cand_cap = (unsigned int)c->cand_cap;
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
+      A.int_weights = c->int_weights ? 1 : 0;
       e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
                              c->band_waves[k], c->lds_bytes[k], A);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
@@ -697,6 +743,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
   if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));
@@ -1087,7 +1134,8 @@ static int faces_enqueue(hc_context* ctx, const uint8_t* d_bgr, size_t frame_str
   if (e) return set_err(HC_ERR_HIP, std::string("face prep launch: ") + hipGetErrorString((hipError_t)e));
   // integral of the mask (sum only) for the skin-ratio post-filter
   const double equiv = (double)nframes * (double)npix / (1280.0 * 720.0);
-  if (ctx->fused_prep > 0 || (ctx->fused_prep < 0 && equiv > ctx->fused_min_batch)) {
+  (void)equiv;
+  if (use_fused_prep(ctx, nframes, false)) {
     e = hc::launch_pyramid_integral(ctx->stream, nframes, 1, ctx->plan.cols, ctx->d_mask, npix, ctx->plan.cols, ctx->plan.rows,
                                     ctx->plan.cols, ctx->d_idlevel, ctx->d_idx, ctx->d_idy, ctx->d_msum, nullptr,
                                     ctx->mask_int_words, nullptr, 0);

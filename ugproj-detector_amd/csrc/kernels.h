@@ -32,6 +32,7 @@ struct CascadeArgs {
   unsigned int* cand_count;
   unsigned int cand_cap;
   int8_t* taps;               // nullable: per-position stage-pass counts
+  int int_weights;            // the node weight words hold int32 (w0 == -1 proven): run the exact-integer build
 };
 
 // YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
