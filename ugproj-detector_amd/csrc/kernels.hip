@@ -202,7 +202,7 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
   uint32_t* rs = rowbuf;
   uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
   uint32_t* xt_s = rowbuf + (size_t)2 * R * lds_pitch;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // uniform by construction: row addresses go scalar
   // the two source rows a destination row interpolates between are staged per wavefront with
   // coalesced dword loads; the 4 bytes per pixel are then gathered from LDS instead of through
   // the (much slower) per-lane byte path of the vector memory unit
@@ -234,9 +234,21 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       const uint8_t* g1 = src + (size_t)oy1 * row_step;
       if (dwords) {
         const int nd = (cols + 3) >> 2;                 // src_pitch is a multiple of 4 >= cols; row_step >= cols
-        for (int i = lane; i < nd; i += 64) {
-          ((uint32_t*)sr0)[i] = ((const uint32_t*)g0)[i];
-          ((uint32_t*)sr1)[i] = ((const uint32_t*)g1)[i];
+        // four pieces of both rows per trip, all eight loads requested before the first LDS store (written as
+        // load -> store per piece the compiler waits for every load separately: ten serial round trips per 1280-pixel row)
+        for (int i0 = lane; i0 < nd; i0 += 64 * 4) {
+          uint32_t a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u;
+            a[u] = i < nd ? ((const uint32_t*)g0)[i] : 0u;
+            b[u] = i < nd ? ((const uint32_t*)g1)[i] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + 64 * u;
+            if (i < nd) { ((uint32_t*)sr0)[i] = a[u]; ((uint32_t*)sr1)[i] = b[u]; }
+          }
         }
       } else {
         for (int i = lane; i < cols; i += 64) { sr0[i] = g0[i]; sr1[i] = g1[i]; }
