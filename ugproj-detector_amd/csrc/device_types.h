@@ -53,7 +53,7 @@ enum NodeKind : int32_t {
   NK_COUNT = 8
 };
 // end[k] = index (relative to DevStage::first) one past the last stump of kind k; end[-1] = 0
-struct DevStageKinds { uint16_t end[NK_COUNT]; };
+struct alignas(16) DevStageKinds { uint16_t end[NK_COUNT]; };   // 16-byte aligned: one scalar load (a 2-byte-aligned record is fetched with a vector load)
 
 // One weak-classifier node, offsets pre-resolved for a TileGeom.
 struct DevNode {

@@ -129,14 +129,25 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_rows(
   uint32_t* S = sum + o;
   uint32_t* Q = sq ? sq + o : nullptr;          // sq == nullptr: sum only (mask integral of the detectFaces path)
   uint32_t carry_s = 0, carry_q = 0;
-  for (int x0 = 0; x0 < w; x0 += 64) {
-    const int x = x0 + lane;
-    const uint32_t p = x < w ? src[x] : 0u;
-    const uint32_t s = wave_scan_u32(p) + carry_s;
-    const uint32_t q = wave_scan_u32(p * p) + carry_q;
-    if (x < w) { S[x] = s; if (Q) Q[x] = q; }
-    carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-    carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+  // four 64-pixel pieces per trip: their loads are in flight together (one piece per trip means one exposed memory
+  // round trip per 64 pixels of the row)
+  for (int x0 = 0; x0 < w; x0 += 64 * 4) {
+    uint32_t px[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int x = x0 + 64 * u + lane;
+      px[u] = x < w ? src[x] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int x = x0 + 64 * u + lane;
+      if (x0 + 64 * u >= w) break;                         // wave-uniform
+      const uint32_t s = wave_scan_u32(px[u]) + carry_s;
+      const uint32_t q = wave_scan_u32(px[u] * px[u]) + carry_q;
+      if (x < w) { S[x] = s; if (Q) Q[x] = q; }
+      carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+      carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+    }
   }
 }
 
