@@ -17,7 +17,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hc::", "").split("<")[0]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hc::", "").replace("casc_int::", "").replace("casc_f32::", "").split("<")[0]
             acc[k][r["Counter_Name"] + "|" + r["Kernel_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
