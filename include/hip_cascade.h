@@ -65,6 +65,14 @@ HC_API int  hc_cascade_dump(const hc_cascade* c, float* stage_thr, int32_t* stag
                             int32_t* tree_nnodes, int32_t* node_rects, float* node_thr,
                             int32_t* node_left, int32_t* node_right, float* leaves);
 
+/* Which cascade this is, and whether the library carries compiled early stages for it: *hash = FNV-1a over window,
+ * stage thresholds, rects, weights, node thresholds and leaves (the fields that decide every result); *nstages = number
+ * of leading stages for which the library holds straight-line device code generated from exactly this cascade
+ * (csrc/spec/, tools/gen_spec.py; stock haarcascade_frontalface_alt and _default), 0 = the generic kernel evaluates every
+ * stage.  Results are identical either way (tests/test_gpu_parity.py, HC_SPEC=0 switches the compiled stages off).
+ * No counterpart in the reference: cv::CascadeClassifier has one evaluation path.  Pure host code. */
+HC_API int  hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages);
+
 /* ---- the call: replaces cv::CascadeClassifier::detectMultiScale
  *      (reference src/tracker/detector.cc:25-31) ------------------------------------------
  * Synchronous, host image in, host rectangles out (the reference's calling convention:
@@ -256,6 +264,9 @@ HC_API int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, 
 HC_API int hc_context_enable_timing(hc_context* ctx, int enable);
 HC_API int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]);
 HC_API const char* hc_kernel_name(int i);
+/* Number of leading stages that ran as compiled code (hc_cascade_compiled_stages) in every cascade launch of the last
+ * enqueued batch; 0 when any of them ran the generic kernel (other cascade, HC_SPEC=0, non-default band shape). */
+HC_API int hc_context_compiled_stages(hc_context* ctx, int* nstages);
 
 HC_API const char* hc_last_error(void);
 HC_API const char* hc_version(void);

@@ -727,3 +727,32 @@ def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, kno
         got = ctx.detect_host(fr[None])
         grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, fr, 0, 1.1, (30, 30))
         assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
+
+
+@pytest.mark.parametrize("name", ["alt", "default"])
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_compiled_early_stages_and_generic_kernel_agree(pkg, oracle, synth, monkeypatch, name, spec):
+    """The stock stump cascades run their first stages as generated straight-line code (csrc/spec/); HC_SPEC=0 sends
+    the same cascade through the generic kernel.  Both must reproduce every tap of the oracle, whole batches and
+    band segments (one frame) alike, and the context must say which of the two actually ran."""
+    monkeypatch.setenv("HC_SPEC", spec)
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    want_n = casc.compiled_stages()[1]
+    assert want_n > 0
+    frames = np.stack([synth.planted(360, 480, synth.frame_seed(40 + i), nfaces=4, min_size=40, max_size=160)[0] for i in range(3)])
+    for batch in (3, 1):
+        ctx = pkg.Context(casc)
+        ctx.configure(360, 480, 1.1, 2, (30, 30), (0, 0), batch, 1 << 15)
+        ctx.enable_stage_taps(True)
+        got = ctx.detect_host(frames[:batch])
+        assert ctx.compiled_stages() == (want_n if spec == "1" else 0)
+        for i in range(batch):
+            grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[i], i, 1.1, (30, 30))
+            assert np.array_equal(ctx.raw_candidates(batch)[i], raw) and np.array_equal(got[i], grouped)
+        # and without the taps (the production instantiation of the kernel)
+        ctx.enable_stage_taps(False)
+        again = ctx.detect_host(frames[:batch])
+        assert ctx.compiled_stages() == (want_n if spec == "1" else 0)
+        for i in range(batch):
+            assert np.array_equal(again[i], got[i])

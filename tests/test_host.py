@@ -257,3 +257,33 @@ int run(const Mat& gray, const Mat& frame) {
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wextra", "-I", os.path.join(root, "tests", "mock_opencv"),
                         "-I", os.path.join(root, "ugproj-detector_amd"), str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_compiled_stages_belong_to_exactly_their_cascade(pkg, oracle, tmp_path):
+    """The library carries generated straight-line code for the early stages of two stock stump cascades (csrc/spec/,
+    tools/gen_spec.py).  It may be used only for a cascade that is bit for bit the one it was generated from: the
+    match is a hash over every number that decides a result.  Host-only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = {}
+    for name, want in (("alt", True), ("default", True), ("alt2", False), ("alt_tree", False)):
+        h, n = pkg.Cascade(oracle.cascade_path(name)).compiled_stages()
+        hashes[name] = h
+        assert (n > 0) == want, (name, n)
+    assert len(set(hashes.values())) == 4
+    # one leaf value changed in the last stage -> different hash, generic kernel
+    raw = bytearray(open(oracle.cascade_path("alt"), "rb").read())
+    raw[-4:] = np.float32(np.frombuffer(bytes(raw[-4:]), np.float32)[0] * np.float32(1.5)).tobytes()
+    mod = tmp_path / "alt_mod.hcc"
+    mod.write_bytes(bytes(raw))
+    h, n = pkg.Cascade(str(mod)).compiled_stages()
+    assert n == 0 and h != hashes["alt"]
+    # the committed generated files are what the generator writes today, and carry the hash the library computes
+    for tag, name in (("alt", "alt"), ("dflt", "default")):
+        inc = os.path.join(root, "ugproj-detector_amd", "csrc", "spec", "spec_%s.inc" % tag)
+        text = open(inc).read()
+        assert "0x%016xull" % hashes[name] in text
+        nst = int(re.search(r"nstages = (\d+)", text).group(1))
+        out = tmp_path / ("spec_%s.inc" % tag)
+        subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag, str(nst), str(out)],
+                              stdout=subprocess.DEVNULL)
+        assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag

@@ -62,6 +62,8 @@ _SIGS = {
     "hc_cascade_free": (None, [C.c_void_p]),
     "hc_cascade_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
     "hc_cascade_counts": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 3),
+    "hc_cascade_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "hc_context_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hc_cascade_dump": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -151,6 +153,12 @@ class Cascade:
             self.close()
         except Exception:
             pass
+
+    def compiled_stages(self):
+        """(model hash, number of leading stages the library holds generated straight-line code for); pure host"""
+        h, n = C.c_uint64(), C.c_int()
+        _check(lib.hc_cascade_compiled_stages(self._h, C.byref(h), C.byref(n)))
+        return h.value, n.value
 
     def dump(self):
         st = np.zeros(self.nstages, np.float32)
@@ -344,6 +352,12 @@ class Context:
         ms = (C.c_float * HC_NKERNELS)()
         _check(lib.hc_context_kernel_ms(self._h, ms))
         return {lib.hc_kernel_name(i).decode(): float(ms[i]) for i in range(HC_NKERNELS)}
+
+    def compiled_stages(self):
+        """leading stages that ran as compiled code in every cascade launch of the last enqueued batch (0: generic kernel)"""
+        n = C.c_int()
+        _check(lib.hc_context_compiled_stages(self._h, C.byref(n)))
+        return n.value
 
     def read_tap(self, frame, level_index, what):
         L = self.levels()[level_index]

@@ -156,6 +156,7 @@ struct hc_context {
   // -1: by batch size (fused above fused_min_batch frames), 0: never fused, 1: always fused (HC_FUSED_PREP)
   int fused_prep = -1;
   bool allow_int_weights = true; // HC_INT_WEIGHTS=0: always the f32 feature arithmetic (A/B, debugging)
+  bool allow_spec = true;        // HC_SPEC=0: never the compiled early stages (csrc/spec), always the generic kernel
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
   int row_stages = 2;            // stages 0 and 1 in row form (conflict-free LDS reads while 88 % of the windows are alive)
@@ -180,6 +181,8 @@ struct hc_context {
   int seg_tiles = 1, seg_max_batch = 8;  // HC_SEG_TILES, HC_SEG_MAX_BATCH (measured: tools/exp_small_batch.sh)
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
   bool int_weights = false;              // every node: w0 == -1, w1 / w2 integers, weighted rect sums below 2^24 (upload_model)
+  int spec_id = 0;                       // compiled early stages matching this model (hc::spec_lookup), 0: none
+  int last_compiled = 0;                 // stages that ran as compiled code in EVERY cascade launch of the last enqueued batch
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;
   hc::DevTree* d_trees = nullptr;
@@ -377,6 +380,22 @@ bool weights_are_small_integers(const hc::Model& m) {
   return true;
 }
 
+// FNV-1a over the fields that decide every result of the cascade, in the order tools/gen_spec.py model_hash walks them:
+// the compiled early stages (csrc/spec/*.inc) carry the hash of the cascade they were generated from.
+unsigned long long model_hash(const hc::Model& m) {
+  unsigned long long h = 0xcbf29ce484222325ull;
+  auto feed = [&](const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+  };
+  const int32_t head[3] = {m.win_w, m.win_h, (int32_t)m.stages.size()};
+  feed(head, sizeof head);
+  for (const hc::ModelStage& s : m.stages) { feed(&s.ntrees, 4); feed(&s.thr, 4); }
+  for (const hc::ModelNode& n : m.nodes) { feed(n.rect, 12); feed(n.weight, 12); feed(&n.thr, 4); }
+  feed(m.leaves.data(), m.leaves.size() * 4);
+  return h;
+}
+
 int upload_model(hc_context* c) {
   const hc::Model& m = c->casc->model;
   std::vector<hc::DevNode> nd[2];
@@ -460,6 +479,7 @@ int upload_model(hc_context* c) {
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   c->int_weights = c->allow_int_weights && weights_are_small_integers(m);
+  c->spec_id = c->int_weights && c->allow_spec && m.is_stump() ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
   if (c->int_weights)
     for (int g = 0; g < 2; g++)
       for (hc::DevNode& d : nd[g])
@@ -600,6 +620,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
+    int launches = 0;
+    c->last_compiled = 0;
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
@@ -617,8 +639,11 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
       A.int_weights = c->int_weights ? 1 : 0;
+      A.spec = c->spec_id;
+      int compiled = 0;
       e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
-                             c->band_waves[k], c->lds_bytes[k], A);
+                             c->band_waves[k], c->lds_bytes[k], A, &compiled);
+      if (A.nbands > 0) c->last_compiled = launches++ == 0 ? compiled : std::min(c->last_compiled, compiled);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
     }
     if (side) {
@@ -677,6 +702,17 @@ int hc_cascade_counts(const hc_cascade* c, int* ntrees, int* nnodes, int* nleave
   if (ntrees) *ntrees = (int)c->model.trees.size();
   if (nnodes) *nnodes = (int)c->model.nodes.size();
   if (nleaves) *nleaves = (int)c->model.leaves.size();
+  return HC_OK;
+}
+
+int hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages) {
+  if (!c) return set_err(HC_ERR_ARG, "null cascade");
+  const hc::Model& m = c->model;
+  const unsigned long long h = model_hash(m);
+  int n = 0;
+  if (m.is_stump() && weights_are_small_integers(m)) (void)hc::spec_lookup(h, m.win_w, m.win_h, &n);
+  if (hash) *hash = (uint64_t)h;
+  if (nstages) *nstages = n;
   return HC_OK;
 }
 
@@ -744,6 +780,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
   if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));
@@ -1351,6 +1388,12 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
 int hc_context_enable_timing(hc_context* ctx, int enable) {
   if (!ctx) return set_err(HC_ERR_ARG, "null context");
   ctx->timing_enabled = enable != 0;
+  return HC_OK;
+}
+
+int hc_context_compiled_stages(hc_context* ctx, int* nstages) {
+  if (!ctx || !nstages) return set_err(HC_ERR_ARG, "null argument");
+  *nstages = ctx->last_compiled;
   return HC_OK;
 }
 

@@ -33,7 +33,18 @@ struct CascadeArgs {
   unsigned int cand_cap;
   int8_t* taps;               // nullable: per-position stage-pass counts
   int int_weights;            // the node weight words hold int32 (w0 == -1 proven): run the exact-integer build
+  int spec;                   // >= 1: id of the compiled early stages matching this cascade (spec_lookup), 0: none
 };
+
+// Compiled early stages of one known cascade (csrc/spec/spec_<tag>.hip): what the generic launcher needs to know.
+struct SpecUnit {
+  unsigned long long hash;   // hc_api.cpp model_hash of the cascade the unit was generated from
+  int win_w, win_h, nstages; // window; number of leading stages compiled
+  // 0 / hipError_t, or -1 when the unit has no kernel for this launch shape (the generic kernel runs then)
+  int (*launch)(hipStream_t st, int nframes, bool segments, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+};
+// id (>= 1) of the unit matching a model, 0 if none; *nstages (nullable) = stages it compiles
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages);
 
 // YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
 struct SkinBounds { int32_t lo[3], hi[3]; };
@@ -77,7 +88,8 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
                     float* vnf, size_t grid_stride);
 // rows = band height in grid rows (8, 16 or 32), nwaves = wavefronts per workgroup (4 or 8);
 // lds_bytes = tile + vnf + 2 queues + counters
+// *compiled (nullable): number of leading stages that ran as compiled code (SpecUnit), 0 for the generic kernel
 int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
-                   const CascadeArgs& args);
+                   const CascadeArgs& args, int* compiled = nullptr);
 
 }  // namespace hc

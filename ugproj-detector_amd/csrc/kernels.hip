@@ -17,25 +17,9 @@
 
 #include "device_types.h"
 #include "kernels.h"
+#include "device_common.h"
 
 namespace hc {
-
-// Read-only tables (levels, work lists, cascade nodes/stages) are addressed through the
-// constant address space: with a wave-uniform index the compiler then emits scalar
-// s_load_* (SGPR operands, scalar cache) instead of per-lane global loads.  The memory is
-// ordinary hipMalloc memory that no kernel writes.
-#define HC_CONST __attribute__((address_space(4)))
-template <class T>
-__device__ __forceinline__ const HC_CONST T* as_const(const T* p) {
-  return (const HC_CONST T*)p;
-}
-
-__device__ __forceinline__ WorkItem load_item(const WorkItem* items, int i) {
-  const HC_CONST WorkItem* c = as_const(items) + i;
-  WorkItem w;
-  w.level = c->level; w.a = c->a; w.b = c->b;
-  return w;
-}
 
 // Inclusive prefix sum over the 64 lanes of a wavefront with DPP (no LDS traffic, no bpermute
 // latency): Hillis-Steele inside each row of 16 lanes (row_shr 1/2/4/8, out-of-row lanes read 0),
@@ -399,7 +383,37 @@ namespace casc_int {
 #define HC_INTW 1
 #include "cascade_body.inc"
 #undef HC_INTW
+
 }  // namespace casc_int
+
+// Compiled early stages (csrc/spec/*.hip, one translation unit per known cascade; spec_unit.inc): the table of units.
+typedef const SpecUnit* (*SpecUnitFn)();
+#if !defined(HC_PHASE) && !defined(HC_OFF_WORDS)
+#define HC_SPEC(tag) const SpecUnit* spec_unit_##tag();
+#include "spec/spec_list.inc"
+#undef HC_SPEC
+static const SpecUnitFn spec_units[] = {
+#define HC_SPEC(tag) spec_unit_##tag,
+#include "spec/spec_list.inc"
+#undef HC_SPEC
+};
+#else
+static const SpecUnitFn spec_units[] = {nullptr};   // instrumented / word-offset builds run the generic kernel only
+#endif
+
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages) {
+  int id = 0;
+  for (const SpecUnitFn fn : spec_units) {
+    id++;
+    const SpecUnit* u = fn ? fn() : nullptr;
+    if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h) {
+      if (nstages) *nstages = u->nstages;
+      return id;
+    }
+  }
+  if (nstages) *nstages = 0;
+  return 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // launchers
@@ -474,10 +488,19 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
 }
 
 int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
-                   const CascadeArgs& args) {
+                   const CascadeArgs& args, int* compiled) {
+  if (compiled) *compiled = 0;
   if (args.nbands == 0 || nframes == 0) return 0;
   // two builds of the same kernel text (cascade_body.inc): rect weights as f32, or -- when the host has shown that every
   // weight is a small integer with w0 == -1 and every weighted rect sum stays below 2^24 -- as exact integer arithmetic
+  // compiled early stages for this cascade (args.spec from spec_lookup); -1: no instance for this launch shape
+  if (args.int_weights && args.spec > 0 && !tree && spec_units[args.spec - 1]) {
+    const int rc = spec_units[args.spec - 1]()->launch(st, nframes, segments, rows, nwaves, lds_bytes, args);
+    if (rc >= 0) {
+      if (compiled) *compiled = spec_units[args.spec - 1]()->nstages;
+      return rc;
+    }
+  }
   return args.int_weights ? casc_int::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args)
                           : casc_f32::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args);
 }
