@@ -180,11 +180,24 @@ __global__ __launch_bounds__(WG_THREADS) void k_integral_cols(
 // registers across chunks, final integral rows stored coalesced.  The pyramid never touches
 // HBM (unless the debug tap asks for it) and `sum`/`sqsum` are written exactly once:
 // HBM traffic = the algorithmic 8 B per integral element.
+// A wave-uniform base pointer plus a 32-bit BYTE offset per lane: the form the global memory instructions take directly
+// (scalar base + 32-bit vector offset), so the access costs no 64-bit address arithmetic on the vector unit.
+__device__ __forceinline__ uint32_t ld_u32_at(const uint32_t* base, uint32_t byte_off) {
+  return *(const uint32_t*)((const char*)base + byte_off);
+}
+__device__ __forceinline__ void st_u32_at(uint32_t* base, uint32_t byte_off, uint32_t v) {
+  *(uint32_t*)((char*)base + byte_off) = v;
+}
+__device__ __forceinline__ void st_f32_at(float* base, uint32_t byte_off, float v) {
+  *(float*)((char*)base + byte_off) = v;
+}
+
 #ifndef HC_PI_THREADS
 #define HC_PI_THREADS 512
 #endif
 constexpr int PI_THREADS = HC_PI_THREADS;   // 8 (16) wavefronts: one pyramid row each per chunk of 8 (16) rows
-constexpr int PI_UNROLL = 4;      // 64-pixel chunks whose source loads are in flight together
+constexpr int PI_UNROLL = 4;      // consecutive pixels per lane in phase 1 (one 16-byte LDS access per quantity)
+static_assert(PI_UNROLL == 4, "phase 1 moves four pixels per lane as one uint4");
 
 template <int CMAX>   // columns per thread: level width <= PI_THREADS * CMAX
 __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
@@ -251,47 +264,81 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       // the same wavefront wrote and now reads the staging rows: LDS operations of one wave execute in
       // order, only the compiler has to be kept from moving the reads up
       __builtin_amdgcn_wave_barrier();
+      // Lane l owns the four consecutive pixels x0 + 4 l .. + 3 of every 256-pixel piece of the row: their prefix is
+      // formed in registers (3 adds, 1 multiply + 3 multiply-adds for the squares), ONE wavefront scan per piece and
+      // quantity spreads the lane totals (a scan per 64 pixels before), and the four row prefixes leave as one 16-byte
+      // LDS store.
       uint32_t carry_s = 0, carry_q = 0;
+      uint32_t* const rs_r = rs + r * lds_pitch;
+      uint32_t* const rq_r = rq + r * lds_pitch;
       for (int x0 = 0; x0 < w; x0 += 64 * PI_UNROLL) {
+        const int x = x0 + 4 * lane;
         uint32_t px[PI_UNROLL];
+        if (x < lds_pitch) {                                // lds_pitch is a multiple of 64 >= w: whole quads
+          const uint4 xq = *(const uint4*)(xt_s + x);
+          const uint32_t xts[4] = {xq.x, xq.y, xq.z, xq.w};
 #pragma unroll
-        for (int u = 0; u < PI_UNROLL; u++) {
-          const int x = x0 + 64 * u + lane;
-          const uint32_t xt = xt_s[min(x, lds_pitch - 1)];
-          const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
-          const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
-          const uint32_t h0 = cx0 * sr0[ox] + cx1 * sr0[ox1];
-          const uint32_t h1 = cx0 * sr1[ox] + cx1 * sr1[ox1];
-          px[u] = x < w ? min((h0 * cy0 + h1 * cy1 + 32768u) >> 16, 255u) : 0u;
-        }
+          for (int u = 0; u < PI_UNROLL; u++) {
+            const uint32_t xt = xts[u];
+            const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
+            const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
+            const uint32_t h0 = cx0 * sr0[ox] + cx1 * sr0[ox1];
+            const uint32_t h1 = cx0 * sr1[ox] + cx1 * sr1[ox1];
+            px[u] = x + u < w ? (h0 * cy0 + h1 * cy1 + 32768u) >> 16 : 0u;   // weights sum to 2^16: the value is <= 255
+          }
+        } else {
 #pragma unroll
-        for (int u = 0; u < PI_UNROLL; u++) {
-          const int x = x0 + 64 * u + lane;
-          if (x0 + 64 * u >= w) break;                   // wave-uniform
-          if (P && x < w) P[(size_t)dy * w + x] = (uint8_t)px[u];
-          const uint32_t s = wave_scan_u32(px[u]) + carry_s;
-          const uint32_t q = wave_scan_u32(px[u] * px[u]) + carry_q;
-          if (x < w) { rs[r * lds_pitch + x] = s; rq[r * lds_pitch + x] = q; }
-          carry_s = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-          carry_q = (uint32_t)__builtin_amdgcn_readlane((int)q, 63);
+          for (int u = 0; u < PI_UNROLL; u++) px[u] = 0u;
         }
+        if (P) {
+#pragma unroll
+          for (int u = 0; u < PI_UNROLL; u++)
+            if (x + u < w) P[(size_t)dy * w + x + u] = (uint8_t)px[u];
+        }
+        uint32_t ps[PI_UNROLL], pq[PI_UNROLL];
+        ps[0] = px[0]; pq[0] = px[0] * px[0];
+#pragma unroll
+        for (int u = 1; u < PI_UNROLL; u++) { ps[u] = ps[u - 1] + px[u]; pq[u] = pq[u - 1] + px[u] * px[u]; }
+        const uint32_t ts = wave_scan_u32(ps[PI_UNROLL - 1]), tq = wave_scan_u32(pq[PI_UNROLL - 1]);   // inclusive over lane totals
+        const uint32_t bs = ts - ps[PI_UNROLL - 1] + carry_s, bq = tq - pq[PI_UNROLL - 1] + carry_q;    // what precedes this lane
+        if (x < lds_pitch) {
+          *(uint4*)(rs_r + x) = make_uint4(ps[0] + bs, ps[1] + bs, ps[2] + bs, ps[3] + bs);
+          *(uint4*)(rq_r + x) = make_uint4(pq[0] + bq, pq[1] + bq, pq[2] + bq, pq[3] + bq);
+        }
+        carry_s += (uint32_t)__builtin_amdgcn_readlane((int)ts, 63);
+        carry_q += (uint32_t)__builtin_amdgcn_readlane((int)tq, 63);
       }
     }
     __syncthreads();
+    {
+      // row bases are wave-uniform pointers, the column a 32-bit lane offset: the stores need no 64-bit address arithmetic
+      uint32_t* const so = S + (size_t)(y0 + 1) * pitch + 1;
+      uint32_t* const qo = Q ? Q + (size_t)(y0 + 1) * pitch + 1 : nullptr;
 #pragma unroll
-    for (int k = 0; k < CMAX; k++) {
-      const int x = threadIdx.x + k * PI_THREADS;
-      if (x < w) {
-        uint32_t cs = col_s[k], cq = col_q[k];
-        uint32_t* so = S + (size_t)(y0 + 1) * pitch + x + 1;
-        uint32_t* qo = Q + (size_t)(y0 + 1) * pitch + x + 1;
-        for (int r = 0; r < nr; r++) {
-          cs += rs[r * lds_pitch + x];
-          cq += rq[r * lds_pitch + x];
-          so[(size_t)r * pitch] = cs;
-          if (Q) qo[(size_t)r * pitch] = cq;
+      for (int k = 0; k < CMAX; k++) {
+        const uint32_t x = threadIdx.x + k * PI_THREADS;
+        if ((int)x < w) {
+          uint32_t cs = col_s[k], cq = col_q[k];
+          int r = 0;
+          for (; r + 4 <= nr; r += 4) {                     // four rows' prefixes requested together
+            uint32_t a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = rs[(r + u) * lds_pitch + x]; b[u] = rq[(r + u) * lds_pitch + x]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              cs += a[u]; cq += b[u];
+              st_u32_at(so + (size_t)(r + u) * pitch, x * 4u, cs);
+              if (qo) st_u32_at(qo + (size_t)(r + u) * pitch, x * 4u, cq);
+            }
+          }
+          for (; r < nr; r++) {
+            cs += rs[r * lds_pitch + x];
+            cq += rq[r * lds_pitch + x];
+            st_u32_at(so + (size_t)r * pitch, x * 4u, cs);
+            if (qo) st_u32_at(qo + (size_t)r * pitch, x * 4u, cq);
+          }
+          col_s[k] = cs; col_q[k] = cq;
         }
-        col_s[k] = cs; col_q[k] = cq;
       }
     }
     __syncthreads();
@@ -306,32 +353,39 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
       int gy_lo = max(y0 - norm_h, 0);
       gy_lo = (gy_lo + ys - 1) / ys;
       const int gy_hi = min((y0 + nr - 1 - norm_h) >= 0 ? (y0 + nr - 1 - norm_h) / ys : -1, gny - 1);
-      const int nrows = gy_hi - gy_lo + 1;
       const double area = (double)(norm_w * norm_h);
       float* vout = vnf + (size_t)frame * grid_stride + L.grid_ofs;
-      // four windows per thread and trip: all 32 integral words are requested before the first is used, so a chunk
-      // pays the L2 round trip once instead of once per window (the march down the largest level is the kernel's
-      // critical path)
+      // Four grid rows per trip: all 32 integral words of a thread's four windows are requested before the first is
+      // used, so a chunk pays the L2 round trip once instead of once per window (the march down the largest level is
+      // the kernel's critical path).  Row bases are wave-uniform pointers and the column a 32-bit lane offset: no
+      // division, no 64-bit address arithmetic per window.
       constexpr int PV = 4;
-      const int total = nrows * gnx;
-      for (int i0 = threadIdx.x; i0 < total; i0 += PV * PI_THREADS) {
-        uint32_t s00[PV], s01[PV], s10[PV], s11[PV], q00[PV], q01[PV], q10[PV], q11[PV];
-        size_t dst[PV];
+      for (int g0 = gy_lo; g0 <= gy_hi; g0 += PV) {
+        const uint32_t *st[PV], *sb[PV], *qt[PV], *qb[PV];
+        float* vo[PV];
 #pragma unroll
         for (int u = 0; u < PV; u++) {
-          const int i = min(i0 + u * PI_THREADS, total - 1);     // clamped: the surplus lanes recompute the last window
-          const int gy = gy_lo + i / gnx, gx = i - (i / gnx) * gnx;
-          const size_t p0 = (size_t)(gy * ys + 1) * pitch + gx * ys + 1, p2 = p0 + (size_t)norm_h * pitch;
-          s00[u] = S[p0]; s01[u] = S[p0 + norm_w]; s10[u] = S[p2]; s11[u] = S[p2 + norm_w];
-          q00[u] = Q[p0]; q01[u] = Q[p0 + norm_w]; q10[u] = Q[p2]; q11[u] = Q[p2 + norm_w];
-          dst[u] = (size_t)gy * gnx + gx;
+          const int gy = min(g0 + u, gy_hi);                   // clamped: a surplus row recomputes the last one
+          const size_t top = (size_t)(gy * ys + 1) * pitch + 1;
+          st[u] = S + top; sb[u] = st[u] + (size_t)norm_h * pitch;
+          qt[u] = Q + top; qb[u] = qt[u] + (size_t)norm_h * pitch;
+          vo[u] = vout + (size_t)gy * gnx;
         }
+        for (uint32_t gx = threadIdx.x; (int)gx < gnx; gx += PI_THREADS) {
+          const uint32_t lo = gx * (uint32_t)ys * 4u, hi = lo + (uint32_t)norm_w * 4u;   // byte offsets
+          uint32_t s00[PV], s01[PV], s10[PV], s11[PV], q00[PV], q01[PV], q10[PV], q11[PV];
 #pragma unroll
-        for (int u = 0; u < PV; u++) {
-          const int valsum = (int)(s00[u] - s01[u] - s10[u] + s11[u]);
-          const uint32_t valsq = q00[u] - q01[u] - q10[u] + q11[u];
-          const float v = vnf_from_sums(valsum, valsq, area);
-          if (i0 + u * PI_THREADS < total) vout[dst[u]] = v;
+          for (int u = 0; u < PV; u++) {
+            s00[u] = ld_u32_at(st[u], lo); s01[u] = ld_u32_at(st[u], hi); s10[u] = ld_u32_at(sb[u], lo); s11[u] = ld_u32_at(sb[u], hi);
+            q00[u] = ld_u32_at(qt[u], lo); q01[u] = ld_u32_at(qt[u], hi); q10[u] = ld_u32_at(qb[u], lo); q11[u] = ld_u32_at(qb[u], hi);
+          }
+#pragma unroll
+          for (int u = 0; u < PV; u++) {
+            const int valsum = (int)(s00[u] - s01[u] - s10[u] + s11[u]);
+            const uint32_t valsq = q00[u] - q01[u] - q10[u] + q11[u];
+            const float v = vnf_from_sums(valsum, valsq, area);
+            if (g0 + u <= gy_hi) st_f32_at(vo[u], gx * 4u, v);
+          }
         }
       }
     }
@@ -443,8 +497,8 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
     R = PI_THREADS / 64;
     while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 + stage > 147456u) R >>= 1;
   }
-  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
+  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
 #define HC_PI(C)                                                                                                  \
   hipLaunchKernelGGL((k_pyramid_integral<C>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                      levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
