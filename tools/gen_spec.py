@@ -19,7 +19,7 @@ import sys
 import numpy as np
 
 TILE_POS = 64
-GROUP = 2
+GROUP = 2        # stumps whose corner reads are issued together
 
 
 def load_hcc(path):
@@ -86,6 +86,34 @@ def stage_exact(leaves):
     return 2 * units < 2 ** 53
 
 
+def stump_corners(n):
+    cs = set()
+    for r in range(3):
+        x, y, w, h = [int(v) for v in n["r"][r]]
+        if r == 2 and int(n["w"][2]) == 0:
+            continue
+        cs |= {(x, y), (x + w, y), (x, y + h), (x + w, y + h)}
+    return cs
+
+
+def order_for_sharing(nodes, ks):
+    """The stumps of a stage, reordered so that the stumps read together (GROUP at a time) share as many rect corners
+    as a greedy choice finds: a shared corner is read once per group.  Legal because only stages whose f64 sum is exact in
+    any order are compiled.  Deterministic (ties go to the lower index)."""
+    cs = {k: stump_corners(nodes[k]) for k in ks}
+    rem, out = list(ks), []
+    while rem:
+        grp = [rem.pop(0)]
+        have = set(cs[grp[0]])
+        while len(grp) < GROUP and rem:
+            best = max(rem, key=lambda k: (len(cs[k] & have), -k))
+            rem.remove(best)
+            grp.append(best)
+            have |= cs[best]
+        out += grp
+    return out
+
+
 def geom(win_w, win_h, ystep, band_rows):
     cols = (TILE_POS - 1) * ystep + win_w + 1
     rows = (band_rows - 1) * ystep + win_h + 1
@@ -132,7 +160,7 @@ def main():
             bsum = sum(float(leaves[2 * k + 1]) for k in range(first[s], first[s + 1]))   # exact in f64 by stage_exact
             L.append("  static __device__ __forceinline__ bool stage%d_y%d(int a, float vnf) {" % (s, ys))
             L.append("    double acc = %s;" % float(bsum).hex())
-            ks = list(range(first[s], first[s + 1]))
+            ks = order_for_sharing(nodes, list(range(first[s], first[s + 1])))
             for g0 in range(0, len(ks), GROUP):
                 grp = ks[g0:g0 + GROUP]
                 corner = {}                      # byte offset -> local name (corners shared inside the group are read once)
