@@ -710,6 +710,7 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_SEG_TILES": "1"},
     {"HC_FUSE_VARIANCE": "0", "HC_FUSED_PREP": "1"},    # fused prep kernel, variance factors by the separate k_variance
     {"HC_INT_WEIGHTS": "0"},                            # f32 feature arithmetic although the cascade qualifies for the integer build
+    {"HC_BANK_ORDER": "0"},                             # sparse finish reads the stumps in the dense path's order
     {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
     {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
 ])

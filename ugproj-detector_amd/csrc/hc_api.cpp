@@ -156,6 +156,7 @@ struct hc_context {
   // -1: by batch size (fused above fused_min_batch frames), 0: never fused, 1: always fused (HC_FUSED_PREP)
   int fused_prep = -1;
   bool allow_int_weights = true; // HC_INT_WEIGHTS=0: always the f32 feature arithmetic (A/B, debugging)
+  bool bank_order = true;        // HC_BANK_ORDER=0: the sparse finish reads the stumps in the dense path's order
   bool allow_spec = true;        // HC_SPEC=0: never the compiled early stages (csrc/spec), always the generic kernel
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
@@ -180,6 +181,7 @@ struct hc_context {
   int n_seg_items[2] = {0, 0};           // bands cut into segments of seg_tiles tiles: the work list of small batches
   int seg_tiles = 1, seg_max_batch = 8;  // HC_SEG_TILES, HC_SEG_MAX_BATCH (measured: tools/exp_small_batch.sh)
   hc::DevNode* d_nodes[2] = {nullptr, nullptr};   // corner offsets resolved for geom[c]
+  hc::DevNode* d_nodes_sparse[2] = {nullptr, nullptr};   // the same records, every exact stage in bank-spreading order (sparse finish)
   bool int_weights = false;              // every node: w0 == -1, w1 / w2 integers, weighted rect sums below 2^24 (upload_model)
   int spec_id = 0;                       // compiled early stages matching this model (hc::spec_lookup), 0: none
   int last_compiled = 0;                 // stages that ran as compiled code in EVERY cascade launch of the last enqueued batch
@@ -380,6 +382,53 @@ bool weights_are_small_integers(const hc::Model& m) {
   return true;
 }
 
+// Sparse finish (one window per wavefront, lane = stump): a wave-instruction reads corner slot j of 64 different stumps of
+// the stage, so which lanes of a 32-lane group collide on an LDS bank is decided by the stumps' own offsets (the window's
+// base shifts all of them alike).  The stage's f64 sum is order-free, so its stumps may be dealt to the 32-lane groups in
+// any order: greedily, each next stump is the one that raises the group's LDS cycles (sum over the corner slots of the
+// fullest bank) least, ties by the fewest bank mates.  In file order a slot costs about 3.5 cycles per group of 32.
+void order_stage_for_banks(std::vector<hc::DevNode>& nodes, int first, int count) {
+  const auto bank = [](const hc::DevNode& n, int j) {
+#ifndef HC_OFF_WORDS
+    return (int)((n.off[j] >> 2) & 31u);
+#else
+    return (int)(n.off[j] & 31u);
+#endif
+  };
+  const auto nslots = [](const hc::DevNode& n) { uint32_t w2; memcpy(&w2, &n.w[2], 4); return w2 ? 12 : 8; };
+  std::vector<hc::DevNode> in(nodes.begin() + first, nodes.begin() + first + count), out;
+  std::vector<char> used(count, 0);
+  out.reserve(count);
+  for (int done = 0; done < count;) {
+    int cnt[12][32] = {};
+    int mx[12] = {};
+    const int gsz = std::min(32, count - done);
+    for (int k = 0; k < gsz; k++) {
+      int best = -1, best_rise = 1 << 30, best_mates = 1 << 30;
+      for (int t = 0; t < count; t++) {
+        if (used[t]) continue;
+        int rise = 0, mates = 0;
+        const int ns = nslots(in[t]);
+        for (int j = 0; j < ns; j++) {
+          const int c0 = cnt[j][bank(in[t], j)];
+          mates += c0;
+          if (c0 + 1 > mx[j]) rise++;
+        }
+        if (rise < best_rise || (rise == best_rise && mates < best_mates)) { best = t; best_rise = rise; best_mates = mates; }
+      }
+      used[best] = 1;
+      const int ns = nslots(in[best]);
+      for (int j = 0; j < ns; j++) {
+        const int b = bank(in[best], j);
+        mx[j] = std::max(mx[j], ++cnt[j][b]);
+      }
+      out.push_back(in[best]);
+      done++;
+    }
+  }
+  std::copy(out.begin(), out.end(), nodes.begin() + first);
+}
+
 // FNV-1a over the fields that decide every result of the cascade, in the order tools/gen_spec.py model_hash walks them:
 // the compiled early stages (csrc/spec/*.inc) carry the hash of the cascade they were generated from.
 unsigned long long model_hash(const hc::Model& m) {
@@ -490,6 +539,16 @@ int upload_model(hc_context* c) {
   int rc;
   if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;
   if ((rc = dev_upload(&c->d_nodes[1], nd[1]))) return rc;
+  {
+    // the sparse finish reads its own copy of the node records: stump stages with an order-free sum in bank-spreading order
+    std::vector<hc::DevNode> ns[2] = {nd[0], nd[1]};
+    if (m.is_stump() && c->bank_order)
+      for (int g = 0; g < 2; g++)
+        for (const hc::DevStage& d : st)
+          if (d.exact) order_stage_for_banks(ns[g], d.first, d.count);
+    if ((rc = dev_upload(&c->d_nodes_sparse[0], ns[0]))) return rc;
+    if ((rc = dev_upload(&c->d_nodes_sparse[1], ns[1]))) return rc;
+  }
   if ((rc = dev_upload(&c->d_stages, st))) return rc;
   if (m.is_stump() && (rc = dev_upload(&c->d_kinds, kinds))) return rc;
   if ((rc = dev_upload(&c->d_trees, tr))) return rc;
@@ -629,7 +688,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.levels = c->d_levels;
       A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
       A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
-      A.nodes = c->d_nodes[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
+      A.nodes = c->d_nodes[k]; A.nodes_sparse = c->d_nodes_sparse[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
       if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
       A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
       A.sparse_max = c->sparse_max;
@@ -781,6 +840,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_BANK_ORDER")) ctx->bank_order = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_SEG_MAX_BATCH")) ctx->seg_max_batch = std::max(0, atoi(e_));
@@ -807,7 +867,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   ctx->free_workspace();
-  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_kinds};
+  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_nodes_sparse[0], ctx->d_nodes_sparse[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_kinds};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -19,6 +19,7 @@ struct CascadeArgs {
   const WorkItem* bands;      // bands of ONE ystep class (all share geometry g)
   int nbands;
   const DevNode* nodes;       // corner offsets resolved for g
+  const DevNode* nodes_sparse; // the same records, exact stump stages in bank-spreading order: read by the sparse finish only
   const DevStage* stages;
   const DevStageKinds* kinds;  // per stage: stumps grouped by NodeKind (null for tree cascades)
   int nstages;
