@@ -730,10 +730,10 @@ def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, kno
         assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
 
 
-@pytest.mark.parametrize("name", ["alt", "default", "alt_tree"])
+@pytest.mark.parametrize("name", ["alt", "default", "alt_tree", "alt2"])
 @pytest.mark.parametrize("spec", ["1", "0"])
 def test_compiled_early_stages_and_generic_kernel_agree(pkg, oracle, synth, monkeypatch, name, spec):
-    """The stock stump cascades run their first stages as generated straight-line code (csrc/spec/); HC_SPEC=0 sends
+    """The stock cascades (three of stumps, alt2 of two-node trees) run their first stages as generated straight-line code (csrc/spec/); HC_SPEC=0 sends
     the same cascade through the generic kernel.  Both must reproduce every tap of the oracle, whole batches and
     band segments (one frame) alike, and the context must say which of the two actually ran."""
     monkeypatch.setenv("HC_SPEC", spec)

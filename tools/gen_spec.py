@@ -8,7 +8,9 @@ The input is a cascade in the package's own HCC1 container (tools/pack_cascade.p
 same numbers as the XML).  The file records an FNV-1a hash of the model (hc_api.cpp model_hash walks the very same fields
 in the same order); the library takes the compiled stages only for a loaded cascade whose hash, window and tile
 geometry match, anything else runs the generic kernel.  Only stages whose f64 sum is exact in any order are compiled
-(same test as hc_api.cpp stage_sum_is_exact) and only integer-weight cascades (weights_are_small_integers).
+(same test as hc_api.cpp stage_sum_is_exact) and only integer-weight cascades (weights_are_small_integers).  Cascades
+of two-node trees (haarcascade_frontalface_alt2: a root, one of whose branches is a leaf) are compiled with both nodes of a
+tree evaluated and the leaf chosen by two selects.
 
 usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 band_rows_ystep2]
 """
@@ -45,7 +47,8 @@ def f32bits(x):
 
 def model_hash(m):
     """FNV-1a 64 over: win_w, win_h, nstages, then per stage ntrees and the f32 bits of the device threshold
-    ((float)thr - 1e-5f in f32), per node 12 rect bytes (as u8), 3 weight words, thr word, then every leaf word."""
+    ((float)thr - 1e-5f in f32), the node count of every tree, per node 12 rect bytes (as u8), 3 weight words, thr word
+    and the two child links, then every leaf word."""
     h = 0xcbf29ce484222325
 
     def feed(bs):
@@ -57,9 +60,12 @@ def model_hash(m):
     for s in m["stages"]:
         thr = np.float32(np.float32(s["thr"]) - np.float32(1e-5))
         feed(struct.pack("<iI", int(s["nt"]), f32bits(thr)))
+    for t in m["tree_nnodes"]:
+        feed(struct.pack("<i", int(t)))
     for n in m["nodes"]:
         feed(bytes(int(v) & 0xff for v in n["r"].reshape(-1)))
         feed(struct.pack("<4I", f32bits(n["w"][0]), f32bits(n["w"][1]), f32bits(n["w"][2]), f32bits(n["thr"])))
+        feed(struct.pack("<2i", int(n["left"]), int(n["right"])))
     for v in m["leaves"]:
         feed(struct.pack("<I", f32bits(v)))
     return h
@@ -127,16 +133,57 @@ def main():
     path, tag, nst, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     band_rows = [int(sys.argv[5]), int(sys.argv[6])] if len(sys.argv) > 6 else [16, 16]
     m = load_hcc(path)
-    if int(m["tree_nnodes"].max()) != 1:
-        raise SystemExit("not a stump cascade")
+    tn = m["tree_nnodes"]
+    if int(tn.max()) == 1:
+        is_tree = False
+    elif int(tn.min()) == 2 and int(tn.max()) == 2:
+        is_tree = True                  # every tree: a root, one of whose branches is a leaf and the other the second node
+    else:
+        raise SystemExit("neither a stump cascade nor one of two-node trees")
     nodes, leaves = m["nodes"], m["leaves"]
     for n in nodes:
         if n["w"][0] != -1.0 or any(float(w) != round(float(w)) or abs(float(w)) > 127 for w in n["w"]):
             raise SystemExit("weights are not small integers")
-    first = np.concatenate([[0], np.cumsum(m["stages"]["nt"])]).astype(int)
+    first = np.concatenate([[0], np.cumsum(m["stages"]["nt"])]).astype(int)        # first tree of a stage
+    nfirst = np.concatenate([[0], np.cumsum(tn)]).astype(int)                        # first node of a tree
+    lfirst = np.concatenate([[0], np.cumsum(tn + 1)]).astype(int)                    # first leaf of a tree
+
+    def tree_terms(t):
+        """(constant leaf, [(leaf difference, ...)]) of tree t such that leaf = constant + sum(selected differences):
+        stump: right + [v < thr] * (left - right); two nodes: other + go * ((lb - other) + [v1 < thr1] * (la - lb))"""
+        n0 = nodes[nfirst[t]]
+        lf = leaves[lfirst[t]:lfirst[t + 1]]
+        if not is_tree:
+            return float(lf[1]), [float(lf[0]) - float(lf[1])], None
+        n1 = nodes[nfirst[t] + 1]
+        l, r = int(n0["left"]), int(n0["right"])
+        if (l > 0) == (r > 0) or max(l, r) != 1 or int(n1["left"]) > 0 or int(n1["right"]) > 0:
+            raise SystemExit("tree %d is not root + one inner child" % t)
+        left_is_node = l > 0
+        other = float(lf[-r]) if left_is_node else float(lf[-l])
+        la, lb = float(lf[-int(n1["left"])]), float(lf[-int(n1["right"])])
+        return other, [lb - other, la - lb], left_is_node
+
+    def stage_exact_terms(s):
+        """every partial sum of constant + selected differences is exact in f64 (all terms multiples of 2^emin, the sum of
+        their magnitudes below 2^53) -- and so is upstream's ordered sum of the leaves themselves"""
+        lv = leaves[lfirst[first[s]]:lfirst[first[s + 1]]]
+        if not stage_exact(lv):
+            return False
+        emin = min(math.frexp(float(v))[1] - 24 for v in lv if float(v) != 0.0) if any(float(v) != 0.0 for v in lv) else 0
+        units = 0
+        for t in range(first[s], first[s + 1]):
+            c, ds, _ = tree_terms(t)
+            for v in [c] + ds:
+                u = math.ldexp(abs(v), -emin)
+                if u != int(u):
+                    return False
+                units += int(u)
+        return units < 2 ** 53
+
     nst = min(nst, len(m["stages"]))
     for s in range(nst):
-        if not stage_exact(leaves[2 * first[s]:2 * first[s + 1]]):
+        if not stage_exact_terms(s):
             nst = s
             break
     L = []
@@ -145,9 +192,15 @@ def main():
     L.append("struct Spec_%s {" % tag)
     L.append("  static constexpr unsigned long long hash = 0x%016xull;" % model_hash(m))
     L.append("  static constexpr int win_w = %d, win_h = %d, nstages = %d;" % (m["win_w"], m["win_h"], nst))
+    L.append("  static constexpr bool is_tree = %s;   // two nodes per tree (the kernel's TREE instantiation)" % ("true" if is_tree else "false"))
     L.append("  static constexpr int band_rows1 = %d, band_rows2 = %d;" % (band_rows[0], band_rows[1]))
     L.append("  static constexpr int pitch1 = %d, pitch2 = %d;   // LDS tile row pitch (words) the offsets below assume" %
              (geom(m["win_w"], m["win_h"], 1, band_rows[0])[0], geom(m["win_w"], m["win_h"], 2, band_rows[1])[0]))
+
+    def dwords(d):
+        bits = struct.unpack("<Q", struct.pack("<d", d))[0]
+        return bits & 0xffffffff, bits >> 32
+
     for ys in (1, 2):
         pitch, half, _ = geom(m["win_w"], m["win_h"], ys, band_rows[ys - 1])
 
@@ -155,43 +208,61 @@ def main():
             col = dx if ys == 1 else ((dx & 1) * half + (dx >> 1))
             return (dy * pitch + col) * 4
 
+        def feature(n, corner):
+            terms = []
+            for r in range(3):
+                x, y, w, h = [int(v) for v in n["r"][r]]
+                wt = int(n["w"][r])
+                if r == 2 and wt == 0:
+                    continue
+                c = [corner.setdefault(o, "c%d" % len(corner)) for o in (off(x, y), off(x + w, y), off(x, y + h), off(x + w, y + h))]
+                if r == 0:
+                    terms.append("(%s + %s - %s - %s)" % (c[1], c[2], c[0], c[3]))
+                else:
+                    terms.append("__mul24(%d, %s - %s - %s + %s)" % (wt, c[0], c[1], c[2], c[3]))
+            return " + ".join(terms[1:] + terms[:1])
+
         for s in range(nst):
             thr = np.float32(np.float32(m["stages"]["thr"][s]) - np.float32(1e-5))
-            bsum = sum(float(leaves[2 * k + 1]) for k in range(first[s], first[s + 1]))   # exact in f64 by stage_exact
+            bsum = sum(tree_terms(t)[0] for t in range(first[s], first[s + 1]))   # exact in f64 by stage_exact_terms
             L.append("  static __device__ __forceinline__ bool stage%d_y%d(int a, float vnf) {" % (s, ys))
             L.append("    double acc = %s;" % float(bsum).hex())
-            ks = order_for_sharing(nodes, list(range(first[s], first[s + 1])))
-            for g0 in range(0, len(ks), GROUP):
-                grp = ks[g0:g0 + GROUP]
-                corner = {}                      # byte offset -> local name (corners shared inside the group are read once)
-                feats, consts = [], []
-                for gi, k in enumerate(grp):
-                    n = nodes[k]
-                    terms = []
-                    for r in range(3):
-                        x, y, w, h = [int(v) for v in n["r"][r]]
-                        wt = int(n["w"][r])
-                        if r == 2 and wt == 0:
-                            continue
-                        c = [corner.setdefault(o, "c%d" % len(corner)) for o in (off(x, y), off(x + w, y), off(x, y + h), off(x + w, y + h))]
-                        if r == 0:
-                            terms.append("(%s + %s - %s - %s)" % (c[1], c[2], c[0], c[3]))
-                        else:
-                            terms.append("__mul24(%d, %s - %s - %s + %s)" % (wt, c[0], c[1], c[2], c[3]))
-                    feats.append(" + ".join(terms[1:] + terms[:1]))
-                    d = float(leaves[2 * k]) - float(leaves[2 * k + 1])
-                    dbits = struct.unpack("<Q", struct.pack("<d", d))[0]
-                    consts.append((f32bits(n["thr"]), dbits & 0xffffffff, dbits >> 32))
-                L.append("    {")
-                for gi, (_, lo, hi) in enumerate(consts):
-                    L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
-                L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
-                L.append("      __builtin_amdgcn_sched_barrier(0);")
-                for gi, f in enumerate(feats):
-                    L.append("      const int f%d = %s;" % (gi, f))
-                for gi, (thrb, _, _) in enumerate(consts):
-                    L.append("      A(acc, vnf, f%d, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
-                L.append("    }")
+            if is_tree:
+                for t in range(first[s], first[s + 1]):                # one tree (two nodes) per read batch
+                    n0, n1 = nodes[nfirst[t]], nodes[nfirst[t] + 1]
+                    _, (d1, d2), left_is_node = tree_terms(t)
+                    corner = {}
+                    f0, f1 = feature(n0, corner), feature(n1, corner)
+                    L.append("    {")
+                    L.append("      int l0, h0; K(l0, h0, 0x%08x, 0x%08x);" % dwords(d1))
+                    L.append("      int l1, h1; K(l1, h1, 0x%08x, 0x%08x);" % dwords(d2))
+                    L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
+                    L.append("      __builtin_amdgcn_sched_barrier(0);")
+                    L.append("      const int f0 = %s;" % f0)
+                    L.append("      const int f1 = %s;" % f1)
+                    L.append("      A2(acc, vnf, f0, 0x%08xu, f1, 0x%08xu, %s, l0, h0, l1, h1);" %
+                             (f32bits(n0["thr"]), f32bits(n1["thr"]), "true" if left_is_node else "false"))
+                    L.append("    }")
+            else:
+                ks = order_for_sharing(nodes, list(range(first[s], first[s + 1])))
+                for g0 in range(0, len(ks), GROUP):
+                    grp = ks[g0:g0 + GROUP]
+                    corner = {}                      # byte offset -> local name (corners shared inside the group are read once)
+                    feats, consts = [], []
+                    for gi, k in enumerate(grp):
+                        n = nodes[k]
+                        feats.append(feature(n, corner))
+                        consts.append((f32bits(n["thr"]),) + dwords(tree_terms(k)[1][0]))
+                    L.append("    {")
+                    for gi, (_, lo, hi) in enumerate(consts):
+                        L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
+                    L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
+                    L.append("      __builtin_amdgcn_sched_barrier(0);")
+                    for gi, f in enumerate(feats):
+                        L.append("      const int f%d = %s;" % (gi, f))
+                    for gi, (thrb, _, _) in enumerate(consts):
+                        L.append("      A(acc, vnf, f%d, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
+                    L.append("    }")
             L.append("    return !(acc < (double)__uint_as_float(0x%08xu));" % f32bits(thr))
             L.append("  }")
         L.append("  static __device__ __forceinline__ bool eval_y%d(int s, int a, float vnf) {" % ys)
@@ -206,7 +277,7 @@ def main():
     L.append("  }")
     L.append("};")
     open(out, "w").write("\n".join(L) + "\n")
-    print("%s: %d stages, %d stumps compiled, hash %016x" % (tag, nst, first[nst], model_hash(m)))
+    print("%s: %d stages, %d %s compiled, hash %016x" % (tag, nst, first[nst], "two-node trees" if is_tree else "stumps", model_hash(m)))
 
 
 if __name__ == "__main__":

@@ -440,7 +440,8 @@ unsigned long long model_hash(const hc::Model& m) {
   const int32_t head[3] = {m.win_w, m.win_h, (int32_t)m.stages.size()};
   feed(head, sizeof head);
   for (const hc::ModelStage& s : m.stages) { feed(&s.ntrees, 4); feed(&s.thr, 4); }
-  for (const hc::ModelNode& n : m.nodes) { feed(n.rect, 12); feed(n.weight, 12); feed(&n.thr, 4); }
+  for (const hc::ModelTree& t : m.trees) feed(&t.nnodes, 4);
+  for (const hc::ModelNode& n : m.nodes) { feed(n.rect, 12); feed(n.weight, 12); feed(&n.thr, 4); feed(&n.left, 4); feed(&n.right, 4); }
   feed(m.leaves.data(), m.leaves.size() * 4);
   return h;
 }
@@ -528,7 +529,7 @@ int upload_model(hc_context* c) {
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   c->int_weights = c->allow_int_weights && weights_are_small_integers(m);
-  c->spec_id = c->int_weights && c->allow_spec && m.is_stump() ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
+  c->spec_id = c->int_weights && c->allow_spec ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
   if (c->int_weights)
     for (int g = 0; g < 2; g++)
       for (hc::DevNode& d : nd[g])
@@ -769,7 +770,7 @@ int hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages
   const hc::Model& m = c->model;
   const unsigned long long h = model_hash(m);
   int n = 0;
-  if (m.is_stump() && weights_are_small_integers(m)) (void)hc::spec_lookup(h, m.win_w, m.win_h, &n);
+  if (weights_are_small_integers(m)) (void)hc::spec_lookup(h, m.win_w, m.win_h, &n);
   if (hash) *hash = (uint64_t)h;
   if (nstages) *nstages = n;
   return HC_OK;

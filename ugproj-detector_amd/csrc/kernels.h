@@ -41,6 +41,7 @@ struct CascadeArgs {
 struct SpecUnit {
   unsigned long long hash;   // hc_api.cpp model_hash of the cascade the unit was generated from
   int win_w, win_h, nstages; // window; number of leading stages compiled
+  bool tree;                 // the cascade has two nodes per tree (k_cascade's TREE instantiation)
   // 0 / hipError_t, or -1 when the unit has no kernel for this launch shape (the generic kernel runs then)
   int (*launch)(hipStream_t st, int nframes, bool segments, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
 };

@@ -548,7 +548,7 @@ int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int ro
   // two builds of the same kernel text (cascade_body.inc): rect weights as f32, or -- when the host has shown that every
   // weight is a small integer with w0 == -1 and every weighted rect sum stays below 2^24 -- as exact integer arithmetic
   // compiled early stages for this cascade (args.spec from spec_lookup); -1: no instance for this launch shape
-  if (args.int_weights && args.spec > 0 && !tree && spec_units[args.spec - 1]) {
+  if (args.int_weights && args.spec > 0 && spec_units[args.spec - 1] && spec_units[args.spec - 1]()->tree == tree) {
     const int rc = spec_units[args.spec - 1]()->launch(st, nframes, segments, rows, nwaves, lds_bytes, args);
     if (rc >= 0) {
       if (compiled) *compiled = spec_units[args.spec - 1]()->nstages;
