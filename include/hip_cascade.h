@@ -66,9 +66,9 @@ HC_API int  hc_cascade_dump(const hc_cascade* c, float* stage_thr, int32_t* stag
                             int32_t* node_left, int32_t* node_right, float* leaves);
 
 /* Which cascade this is, and whether the library carries compiled early stages for it: *hash = FNV-1a over window,
- * stage thresholds, rects, weights, node thresholds and leaves (the fields that decide every result); *nstages = number
+ * stage thresholds, tree sizes, rects, weights, node thresholds, child links and leaves (the fields that decide every result); *nstages = number
  * of leading stages for which the library holds straight-line device code generated from exactly this cascade
- * (csrc/spec/, tools/gen_spec.py; stock haarcascade_frontalface_alt, _default and _alt_tree), 0 = the generic kernel evaluates every
+ * (csrc/spec/, tools/gen_spec.py; all four stock cascades), 0 = the generic kernel evaluates every
  * stage.  Results are identical either way (tests/test_gpu_parity.py, HC_SPEC=0 switches the compiled stages off).
  * No counterpart in the reference: cv::CascadeClassifier has one evaluation path.  Pure host code. */
 HC_API int  hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages);
