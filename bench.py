@@ -8,6 +8,8 @@ the timed region starts.  Workloads (`--config`, BASELINE.json `configs`):
     minNeighbors 2, minSize 30x30 -- the literal call at reference src/tracker/detector.cc:25-31;
   3: 1920x1080, alt2 + default on the same frames (two-cascade pass);
   5: 3840x2160, all four data/ cascades on the same frames.
+The default single-GPU run measures config 2 (that is `value`) and then, outside its timed
+region, a few steps of configs 3 and 5 with their own oracle check (`extra.configs`).
 Frames shard across ranks (one process per GPU, weak scaling); the only collective is the RCCL
 all-gather of box records back to rank 0 (ugproj-detector_amd/shard.py), lossless for any number
 of boxes per frame.
@@ -26,22 +28,24 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # oracle_lib: the checker and the cpu_baseline leg only
 
 CALL = dict(scale_factor=1.1, min_neighbors=2, min_size=(30, 30), max_size=(0, 0))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 CONFIGS = {
-    2: dict(rows=720, cols=1280, cascades=("alt",), batch=256, cpu_sample=32, parity_frames=4,
+    2: dict(rows=720, cols=1280, cascades=("alt",), batch=256, cpu_sample=256, parity_frames=16,
             label="BASELINE config #2: 1280x720 gray, haarcascade_frontalface_alt"),
-    3: dict(rows=1080, cols=1920, cascades=("alt2", "default"), batch=96, cpu_sample=16, parity_frames=2,
+    3: dict(rows=1080, cols=1920, cascades=("alt2", "default"), batch=96, cpu_sample=32, parity_frames=4,
             label="BASELINE config #3: 1920x1080 gray, haarcascade_frontalface_alt2 + _default on the same frames"),
     5: dict(rows=2160, cols=3840, cascades=("alt", "alt2", "alt_tree", "default"), batch=32, cpu_sample=8, parity_frames=1,
             label="BASELINE config #5: 3840x2160 gray, all four data/ cascades on the same frames"),
 }
+EXTRA_CONFIGS = (3, 5)         # measured after the headline, a few steps each (`extra.configs`)
 
 
 def parse_args(argv=None):
@@ -56,6 +60,8 @@ def parse_args(argv=None):
     ap.add_argument("--cascade", default="", help="override the config's cascade list (comma separated)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs leg (configs 3 and 5 after the headline)")
+    ap.add_argument("--extra-steps", type=int, default=5)
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="1: both pipeline slots on one stream (clean per-kernel times); 2: a stream per slot")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -63,6 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: ranks share the visible GPUs (rank r -> device r mod count); needs --backend gloo")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the gather even with one rank")
+    ap.add_argument("--spawn-timeout", type=float, default=1500.0, help="seconds before self-spawned ranks are terminated")
     return ap.parse_args(argv)
 
 
@@ -77,7 +84,7 @@ def free_port():
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this same script
     (fresh interpreters, this parent never initialises HIP and never execs), relay rank 0's JSON
-    line, fail if any rank fails."""
+    line, fail if any rank fails or the run exceeds --spawn-timeout."""
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -86,23 +93,40 @@ def spawn_ranks(args):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout
+    # rank 0's stdout is drained while the ranks run: a rank that prints more than a pipe buffer (library or RCCL
+    # debug output) would otherwise block in write() with the other ranks waiting for it in a collective
     lines = []
-    failed = None
+
+    def drain():
+        for raw in procs[0].stdout:
+            lines.append(raw.decode(errors="replace").rstrip("\n"))
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    failed, timed_out = None, False
+    deadline = time.monotonic() + args.spawn_timeout
     while True:
         codes = [p.poll() for p in procs]
         bad = [i for i, c in enumerate(codes) if c not in (None, 0)]
-        if bad and failed is None:
-            failed = bad[0]
+        if failed is None and (bad or time.monotonic() > deadline):
+            failed = bad[0] if bad else -1
+            timed_out = not bad
             for p in procs:                      # exact PIDs we started, nothing else
                 if p.poll() is None:
                     p.terminate()
+            deadline = time.monotonic() + 20
+        elif failed is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
         if all(c is not None for c in codes):
             break
         time.sleep(0.05)
-    lines = out0.read().decode(errors="replace").splitlines()
+    reader.join(timeout=10)
     if failed is not None:
-        sys.stderr.write("bench.py: rank %d exited with code %d\n" % (failed, procs[failed].returncode))
+        if timed_out:
+            sys.stderr.write("bench.py: ranks still running after %.0f s -- terminated\n" % args.spawn_timeout)
+        else:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (failed, procs[failed].returncode))
         sys.stderr.write("\n".join(lines) + "\n")
         raise SystemExit(1)
     js = [ln for ln in lines if ln.startswith("{")]
@@ -127,7 +151,12 @@ def load_package():
     return mod
 
 
-def make_frames_parallel(synth, kind, n, rows, cols, first):
+def host_threads(world):
+    """this rank's share of the node's host cores (the GPU box grants 16 per GPU): frame generator, oracle checker"""
+    return max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+
+
+def make_frames_parallel(synth, kind, n, rows, cols, first, nthreads):
     """n distinct frames (global ids first .. first+n-1), generated on a thread pool (numpy releases the GIL)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
@@ -135,57 +164,82 @@ def make_frames_parallel(synth, kind, n, rows, cols, first):
 
     def one(i):
         out[i] = synth.make_frames(kind, 1, rows, cols, first=first + i)[0]
-    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=nthreads) as ex:
         list(ex.map(one, range(n)))
     return out
 
 
-def rank_main(args):
+class Env:
+    """what one rank process sets up once: device, process group, modules"""
+    pass
+
+
+def setup(args):
     import importlib
-    import numpy as np
     import torch   # must come before the HIP library: both bind the same libamdhip64.so.7
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
+    E = Env()
+    E.torch, E.dist = torch, dist
+    E.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    E.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if E.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, E.world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    ndev = torch.cuda.device_count()
-    if local_rank >= ndev:
+    E.ndev = torch.cuda.device_count()
+    if local_rank >= E.ndev:
         if not (args.share_gpu and args.backend == "gloo"):
             raise SystemExit("rank %d has no GPU of its own (%d visible): one process per GPU "
-                             "(rehearse with --share-gpu --backend gloo)" % (local_rank, ndev))
-    devno = local_rank % ndev
-    torch.cuda.set_device(devno)
-    dev = torch.device("cuda", devno)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
+                             "(rehearse with --share-gpu --backend gloo)" % (local_rank, E.ndev))
+    E.devno = local_rank % E.ndev
+    E.shared = E.world > E.ndev                      # several ranks per device: a rehearsal, never a scaling point
+    torch.cuda.set_device(E.devno)
+    E.dev = torch.device("cuda", E.devno)
+    E.use_dist = E.world > 1 or args.force_dist
+    E.nthreads = host_threads(E.world)
+    # the library's own post-processing pool (candidate decode + grouping per frame) gets its share too
+    os.environ.setdefault("HC_HOST_THREADS", str(max(1, min(4, E.nthreads))))
+    if E.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=E.dev)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+    E.pkg = load_package()
+    E.synth = importlib.import_module("ugproj_detector_amd.synth")
+    E.shard = importlib.import_module("ugproj_detector_amd.shard")
+    import oracle_lib                               # test infrastructure: parity check before timing, cpu_baseline
+    E.oracle = oracle_lib
+    if args.streams == 1:
+        # one explicit (non-default) stream shared by all contexts: kernels of consecutive batches run back
+        # to back, never concurrently, so the per-kernel HIP-event times are clean
+        torch.cuda.set_stream(torch.cuda.Stream(device=E.dev))
+        E.stream = torch.cuda.current_stream().cuda_stream
+    else:
+        E.stream = None   # each context owns a stream: kernels of batch i+1 may overlap the tail of batch i
+    return E
 
-    pkg = load_package()
-    synth = importlib.import_module("ugproj_detector_amd.synth")
-    shard = importlib.import_module("ugproj_detector_amd.shard")
-    import oracle_lib
 
-    cfg = CONFIGS[args.config]
+def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1, timing=True):
+    """One workload, measured: returns the result dict on rank 0 (None elsewhere)."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    torch, dist, pkg, synth, shard, oracle_lib = E.torch, E.dist, E.pkg, E.synth, E.shard, E.oracle
+    rank, world, dev = E.rank, E.world, E.dev
+    cfg = CONFIGS[cfgno]
     rows, cols = cfg["rows"], cfg["cols"]
-    names = tuple(args.cascade.split(",")) if args.cascade else cfg["cascades"]
-    B = args.batch or cfg["batch"]
-    cpaths = [oracle_lib.cascade_path(n) for n in names]
+    names = tuple(names) if names else cfg["cascades"]
+    B = batch or cfg["batch"]
+    cpaths = [pkg.cascade_path(n) for n in names]
     cascs = [pkg.Cascade(p) for p in cpaths]
 
     # ---- synthetic frames: rank r owns global frames [r*B, (r+1)*B) of every step's global batch; its
     # `ndist` distinct frames are the global synthetic frames r*ndist .. (r+1)*ndist-1 (SplitMix64 per index)
     ndist = min(args.distinct or B, B)
-    distinct = make_frames_parallel(synth, args.kind, ndist, rows, cols, first=rank * ndist)
+    distinct = make_frames_parallel(synth, args.kind, ndist, rows, cols, first=rank * ndist, nthreads=E.nthreads)
     frames_np = distinct[np.arange(B) % ndist]
     d_frames = torch.from_numpy(frames_np).to(dev)
     torch.cuda.synchronize()
@@ -193,16 +247,9 @@ def rank_main(args):
     # Two pipeline slots (workspaces): batch i+1 is enqueued before batch i is waited for, so the host-side
     # candidate decode / rectangle grouping / record packing of batch i overlaps the kernels of batch i+1.
     # Every step still does all of its work.  A slot holds one context per cascade of the config.
-    if args.streams == 1:
-        # one explicit (non-default) stream shared by all contexts: kernels of consecutive batches run back
-        # to back, never concurrently, so the per-kernel HIP-event times are clean
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
-        stream = torch.cuda.current_stream().cuda_stream
-    else:
-        stream = None   # each context owns a stream: kernels of batch i+1 may overlap the tail of batch i
     slots = []
     for _ in range(2):
-        cs = [pkg.Context(casc, device=devno, stream=stream) for casc in cascs]
+        cs = [pkg.Context(casc, device=E.devno, stream=E.stream) for casc in cascs]
         if len(cs) == 1:
             cs[0].configure(rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
                             max_batch=B, cand_capacity=4096)
@@ -216,8 +263,9 @@ def rank_main(args):
 
     # the gather of box records runs on its own stream: it must not queue behind the kernels of the next
     # batch that are already enqueued on the compute stream
-    comm_stream = torch.cuda.Stream(device=dev) if (use_dist and args.backend == "nccl") else None
-    gatherer = shard.BoxGatherer(dev if (use_dist and args.backend == "nccl") else None)
+    rccl = E.use_dist and args.backend == "nccl"
+    comm_stream = torch.cuda.Stream(device=dev) if rccl else None
+    gatherer = shard.BoxGatherer(dev if rccl else None)
 
     def enqueue(slot):
         for c in slot:
@@ -258,7 +306,8 @@ def rank_main(args):
         allb = gatherer.finish()
         return res, allb
 
-    run_steps(args.warmup)
+    if warmup > 0:
+        run_steps(warmup)
 
     # ---- parity of what is being timed, before any timing: rank 0 checks frames OF EVERY RANK, as they
     # arrive through the gather, against the CPU oracle (the frames are a pure function of their global index)
@@ -266,24 +315,28 @@ def rank_main(args):
     parity = None
     if rank == 0:
         ocs = [oracle_lib.OracleCascade(p) for p in cpaths]
-        ok, nb, nchk = True, 0, 0
-        per_rank = min(cfg["parity_frames"], 2 if world > 1 else 4, ndist)
-        for r in range(world):
-            for f in range(min(per_rank, ndist)):
-                fr = frames_np[f] if r == 0 else synth.make_frames(args.kind, 1, rows, cols, first=r * ndist + f)[0]
-                want = np.concatenate([oc.detect(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0]
-                                       for oc in ocs])
-                got = gathered[r * B + f]          # global frame id of step 0: (0 * world + r) * B + f
-                ok = ok and np.array_equal(got, want)
-                nb += len(want)
-                nchk += 1
-        ok = ok and sorted(gathered) == list(range(world * B))
-        parity = {"frames_checked": nchk, "ranks_checked": world, "boxes": nb, "bit_exact": bool(ok),
-                  "gathered_frames": len(gathered)}
+        per_rank = min(cfg["parity_frames"] if world == 1 else max(2, 16 // world), ndist)
+        jobs = [(r, f) for r in range(world) for f in range(per_rank)]
+
+        def check(job):
+            r, f = job
+            fr = frames_np[f] if r == 0 else synth.make_frames(args.kind, 1, rows, cols, first=r * ndist + f)[0]
+            if len(jobs) >= E.nthreads or len(ocs) == 1:
+                per = [oc.detect(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0] for oc in ocs]
+            else:        # few large frames, several cascades (config 5): the cascades of a frame side by side
+                with ThreadPoolExecutor(max_workers=len(ocs)) as ex2:
+                    per = list(ex2.map(lambda oc: oc.detect(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0], ocs))
+            want = np.concatenate(per)
+            got = gathered[r * B + f]          # global frame id of step 0: (0 * world + r) * B + f
+            return bool(np.array_equal(got, want)), len(want)
+        with ThreadPoolExecutor(max_workers=E.nthreads) as ex:      # the oracle call releases the GIL
+            res = list(ex.map(check, jobs))
+        ok = all(r[0] for r in res) and sorted(gathered) == list(range(world * B))
+        parity = {"frames_checked": len(jobs), "ranks_checked": world, "boxes": int(sum(r[1] for r in res)),
+                  "bit_exact": bool(ok), "gathered_frames": len(gathered)}
         if not ok and not os.environ.get("HC_DEBUG_MAX_STAGES"):
             raise SystemExit("bench: HIP boxes differ from the oracle -- refusing to report a number")
 
-    timing = not args.no_timing_events
     for s in slots:
         for c in s:
             c.enable_timing(timing)
@@ -296,42 +349,58 @@ def rank_main(args):
                     kernel_ms[k] = kernel_ms.get(k, 0.0) + v
 
     def barrier():
-        if use_dist:
+        if E.use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     barrier()
     t0 = time.perf_counter()
-    run_steps(args.steps, collect)
+    run_steps(steps, collect)
+    own = time.perf_counter() - t0             # this rank's own K steps (before it waits for the others)
     barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    rank_s = [own]
+    if E.use_dist:
+        cdev = dev if args.backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([own], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_s = [float(x.item()) for x in every]
     for s in slots:
         for c in s:
             c.enable_timing(False)
 
+    out = None
     if rank == 0:
-        fps = world * B * args.steps / elapsed
+        fps = world * B * steps / elapsed
         cnames = " + ".join("haarcascade_frontalface_%s" % n for n in names)
+        if not E.use_dist:
+            par = "single GPU: no process group, no collective (box records packed and unpacked locally)"
+        else:
+            par = "frame-shard x%d, %s all-gather of box records" % (world, "RCCL" if args.backend == "nccl" else "gloo")
         out = {
             "metric": "%dp frames/sec, %s, boxes bit-exact vs CPU oracle" % (rows, cnames),
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": min(world, E.ndev) if E.shared else world,
+            "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 integrals, f32 features, f64 stage sums", "data": "synthetic",
             "config": {"workload": "%s, scaleFactor 1.1, minNeighbors 2, minSize 30x30, S3 '%s' frames"
-                                   % (cfg["label"] if not args.cascade else "%dx%d gray, %s" % (cols, rows, cnames), args.kind),
+                                   % (cfg["label"] if names == cfg["cascades"] else "%dx%d gray, %s" % (cols, rows, cnames), args.kind),
                        "frames_per_gpu_per_step": B, "distinct_frames_per_gpu": ndist,
                        "levels": [sum(1 for L in c.levels() if L.nx > 0) for c in slots[0]],
                        "shared_prep_levels": len(slots[0][0].levels()) if len(slots[0]) > 1 else None,
-                       "parallelism": "frame-shard x%d, %s all-gather of box records"
-                                      % (world, "RCCL" if args.backend == "nccl" else "gloo")},
+                       "parallelism": par},
             "parity": parity,
+            "per_rank_fps": [round(B * steps / s, 1) for s in rank_s],
         }
-        if timing and kernel_ms:
-            per_launch = {k: v / args.steps for k, v in kernel_ms.items()}
+        if E.shared:
+            out["rehearsal"] = True              # ranks share a device: exercises the N > 1 code path, says nothing about scaling
+            out["ranks"] = world
+        if timing and kernel_ms and not E.shared:
+            per_launch = {k: v / steps for k, v in kernel_ms.items()}
             dom = max(per_launch, key=per_launch.get)
             achieved = alg_bytes * B / (per_launch[dom] * 1e-3) / 1e9
             # HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
@@ -340,7 +409,7 @@ def rank_main(args):
             traffic, traffic_src = None, None
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if tf and args.kind == "planted" and args.config == 2 and not args.cascade:
+            if tf and args.kind == "planted" and cfgno == 2 and names == cfg["cascades"]:
                 try:
                     tj = json.load(open(tf[-1]))
                     traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"] * B / tj.get("frames_per_launch", 64))
@@ -353,8 +422,9 @@ def rank_main(args):
                                "algorithmic_bytes_per_launch": alg_bytes * B,
                                "launch_ms": round(per_launch[dom], 4),
                                "all_kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()}}
-        ns = cfg["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
-        if ns > 0 and world == 1:
+        ns = cfg["cpu_sample"] if cpu_sample < 0 else cpu_sample
+        if ns > 0:
+            # reported at any N: rank 0's host cores, the same frames (the other ranks wait at the closing barrier)
             cores = min(os.cpu_count() or 1, 16)   # the GPU box grants a 16-core CPU share per GPU
             sample = distinct[np.arange(ns) % ndist]
             ocs = [oracle_lib.OracleCascade(p) for p in cpaths]
@@ -365,10 +435,45 @@ def rank_main(args):
             out["cpu_baseline"] = {"value": round(ns / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d of the same %dx%d '%s' frames through %s, frame-parallel over %d threads, "
                                              "%.1f s wall" % (ns, cols, rows, args.kind, cnames, cores, dt)}
+    for s in slots:
+        for c in s:
+            c.close()
+    del d_frames
+    torch.cuda.empty_cache()
+    return out
+
+
+def rank_main(args):
+    E = setup(args)
+    names = tuple(args.cascade.split(",")) if args.cascade else None
+    out = run_config(E, args, args.config, args.steps, args.warmup, batch=args.batch, names=names, cpu_sample=args.cpu_sample,
+                     timing=not args.no_timing_events)
+    # Driver-visible numbers for BASELINE configs #3 and #5: only in the plain single-GPU default run, after the headline
+    # measurement, never inside its timed region; a few steps each with their own oracle check.
+    plain = (E.world == 1 and not args.force_dist and args.config == 2 and not args.cascade and not args.batch
+             and not args.distinct and args.kind == "planted" and not args.no_extra
+             and not os.environ.get("HC_DEBUG_MAX_STAGES"))
+    if plain:
+        extra = {}
+        for cno in EXTRA_CONFIGS:
+            t0 = time.perf_counter()
+            try:
+                r = run_config(E, args, cno, args.extra_steps, 1, cpu_sample=0, timing=True)
+                extra[str(cno)] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"],
+                                   "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                                   "frames_per_step": r["config"]["frames_per_gpu_per_step"],
+                                   "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "launch_ms",
+                                                                              "all_kernels_ms_per_launch")},
+                                   "parity": r["parity"], "wall_s": round(time.perf_counter() - t0, 1)}
+            except BaseException as e:       # the headline line is still printed; the failure is part of the record
+                extra[str(cno)] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if out is not None:
+            out["extra"] = {"configs": extra}
+    if E.rank == 0:
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if E.use_dist:
+        E.dist.barrier()
+        E.dist.destroy_process_group()
 
 
 def main():

@@ -79,7 +79,12 @@ HC_API int  hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int*
  * one frame at a time from one thread, src/tracker/face_tracker.cc:93-152).
  * `flags` is accepted and ignored exactly as OpenCV >= 4 ignores it for this path.
  * max_w/max_h == 0 means "image size" (cv::Size()).  `out` is overwritten.
- * Uses an internal per-cascade context on the current HIP device. */
+ * Uses internal per-cascade contexts on the current HIP device, one per (frame geometry, call parameters) and a few
+ * of them cached (HC_SYNC_CONTEXTS, default 4, least recently used one re-configured): a caller alternating between
+ * a few image sizes allocates nothing after the first call of each.
+ * When the rectangles do not fit `out`: HC_ERR_CAPACITY, *out_count = the number found, and
+ * hc_detect_multiscale_reread hands them over without running the detection again (all synchronous calls on a
+ * cascade share this: hc_detect_multiscale[_image], hc_detect_multiscale_cv24[_taps], hc_detect_faces). */
 HC_API int hc_detect_multiscale(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes,
                                 double scale_factor, int min_neighbors, int flags,
                                 int min_w, int min_h, int max_w, int max_h,
@@ -93,6 +98,7 @@ HC_API int hc_detect_multiscale_image(hc_cascade* c, const uint8_t* image, int r
                                       size_t step_bytes, double scale_factor, int min_neighbors, int flags,
                                       int min_w, int min_h, int max_w, int max_h,
                                       hc_rect* out, int out_capacity, int* out_count);
+HC_API int hc_detect_multiscale_reread(hc_cascade* c, hc_rect* out, int out_capacity, int* out_count);
 /* cvtColor(image, gray, COLOR_BGR2GRAY) alone (reference src/tracker/detector.cc:20), host in / host out, on the
  * current device: (3735 B + 19235 G + 9798 R + 16384) >> 15.  channels = 3 or 4. */
 HC_API int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int channels, size_t step_bytes,
@@ -147,8 +153,9 @@ HC_API int  hc_context_configure(hc_context* ctx, int rows, int cols, double sca
  * alone, so one pyramid + integral pass over the union of the cascades' scale ladders serves them all: ctxs[0]
  * (the leader) owns those integrals, the other contexts (followers) only run their own variance and cascade
  * kernels on them.  Per batch: enqueue the leader first, then each follower once with the same batch (a
- * follower takes the frames from the leader's pass; its frame pointer argument is ignored), then wait on each
- * context for its cascade's rectangles.  Cross-stream ordering (followers behind the leader's prep kernels, the
+ * follower takes the frames from the leader's pass; its frame pointer argument names the batch and must equal the
+ * one the leader got -- HC_ERR_STATE otherwise, e.g. when the leader was enqueued again before this follower had
+ * scanned the previous batch), then wait on each context for its cascade's rectangles.  Cross-stream ordering (followers behind the leader's prep kernels, the
  * leader's next batch behind the followers' scans) is handled with events, so the contexts may own their
  * streams or share one.  Reconfiguring or destroying the leader leaves the followers unconfigured.
  * hc_context_algorithmic_bytes stays each cascade's own full figure (sharing is an optimisation, not a
@@ -158,9 +165,18 @@ HC_API int  hc_context_configure_shared(hc_context* const* ctxs, int n, int rows
                                         int min_neighbors, int min_w, int min_h, int max_w, int max_h,
                                         int max_batch, int cand_capacity);
 /* Enqueue detection of nframes 8-bit gray frames that already live in device memory
- * (frame f at d_frames + f*frame_stride_bytes, rows row_step_bytes apart). Asynchronous. */
+ * (frame f at d_frames + f*frame_stride_bytes, rows row_step_bytes apart). Asynchronous.
+ * Frame lifetime: the kernels read d_frames in stream order, so the buffer may be recycled behind the batch on the
+ * same stream (a double-buffered decoder).  The one exception is a batch that yields more raw candidates than the
+ * workspace holds (cand_capacity): hc_detect_batch_wait then grows the workspace and
+ *   - by default returns HC_ERR_CAND_OVERFLOW -- nothing was lost, enqueue the same batch again;
+ *   - after hc_context_set_rerun_on_overflow(ctx, 1) re-reads d_frames and runs the batch again by itself: the
+ *     caller thereby promises to keep the frames valid and unmodified until the wait returns.
+ * Host-input batches (hc_detect_batch_enqueue_host, the synchronous calls, the detectFaces path) are staged in the
+ * context's own memory and always re-run by themselves.  Same rule for hc_faces_batch_enqueue. */
 HC_API int  hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes,
                                     size_t row_step_bytes, int nframes);
+HC_API int  hc_context_set_rerun_on_overflow(hc_context* ctx, int allow);
 /* Same, from host memory (adds the H2D copy on the context stream; one copy for the whole batch when the
  * frames are tight and contiguous).  The copy is truly asynchronous -- and about 4x faster -- when the
  * frames live in page-locked memory: either allocate the frame pool with hc_host_alloc, or pin a pool the
@@ -267,6 +283,10 @@ HC_API const char* hc_kernel_name(int i);
 /* Number of leading stages that ran as compiled code (hc_cascade_compiled_stages) in every cascade launch of the last
  * enqueued batch; 0 when any of them ran the generic kernel (other cascade, HC_SPEC=0, non-default band shape). */
 HC_API int hc_context_compiled_stages(hc_context* ctx, int* nstages);
+
+/* Device and pinned-host allocations the library has made in this process so far (hipMalloc / hipHostMalloc
+ * calls): tests use it to show that a steady state allocates nothing. */
+HC_API long long hc_debug_alloc_count(void);
 
 HC_API const char* hc_last_error(void);
 HC_API const char* hc_version(void);

@@ -13,13 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "libhaar_oracle.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "ugproj-detector_amd", "data")     # the packed cascades ship with the product package
 CASCADE_NAMES = ("alt", "alt2", "alt_tree", "default")
 
 
 def cascade_path(name, xml=False):
     if xml:
         return "/root/reference/data/haarcascade_frontalface_%s.xml" % name
-    return os.path.join(GOLDEN, "cascades", "haarcascade_frontalface_%s.hcc" % name)
+    return os.path.join(DATA, "cascades", "haarcascade_frontalface_%s.hcc" % name)
 
 
 def build():

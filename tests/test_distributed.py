@@ -1,4 +1,4 @@
-"""Multi-process path on CPU: world_size 2 (and 3) over gloo.  Frames shard in contiguous blocks,
+"""Multi-process path on CPU: world_size 2, 3 and 8 over gloo.  Frames shard in contiguous blocks,
 no data-path collective; the only exchange is the all-gather of fixed-capacity box records
 (ugproj-detector_amd/shard.py), which must return every frame's boxes tagged with its frame id --
 the tracker consumes frames in order (reference src/tracker/face_tracker.cc:123-148)."""
@@ -59,7 +59,7 @@ def test_pack_unpack_roundtrip(pkg):
         assert got[fid].tolist() == b.tolist()
 
 
-@pytest.mark.parametrize("world,overflow", [(2, True), (3, True), (2, False)])
+@pytest.mark.parametrize("world,overflow", [(2, True), (3, True), (2, False), (8, True)])
 def test_gloo_gather_of_box_records(pkg, tmp_path, world, overflow):
     """Every box of every frame of every rank arrives at rank 0, addressable by global frame id -- including
     frames with more than MAX_BOXES boxes (second, variable-length all-gather; ranks overflow by different
@@ -119,3 +119,7 @@ def test_bench_spawns_its_own_ranks_and_reports_failures(pkg):
     assert r.returncode != 0
     assert "rank" in r.stderr and "MI355X" in r.stderr, r.stderr[-1500:]
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a run that does not finish is ended by the parent (exact PIDs it started) instead of hanging the driver
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--spawn-timeout", "0.05"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "terminated" in r.stderr, r.stderr[-1500:]

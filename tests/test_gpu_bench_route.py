@@ -69,6 +69,23 @@ def test_bench_route_taps_720p_batch24(pkg, oracle, synth):
         img = oracle.resize_linear_exact(frames[13], L.h, L.w)
         s, q = oracle.integral(img)
         assert np.array_equal(ctx.read_tap(13, li, pkg.TAP_SUM), s) and np.array_equal(ctx.read_tap(13, li, pkg.TAP_SQSUM), q)
+    # The instantiation BENCH_rNN.json times has the stage taps compiled OUT (k_cascade<.., TAPS = false, ..>): the same
+    # 24 frames again without taps, raw candidates (canonical order) and grouped boxes of every frame.
+    ctx.enable_stage_taps(False)
+    assert ctx.compiled_stages() > 0, "the stock cascade must run its compiled early stages on this route"
+    got2 = ctx.detect_host(frames)
+    raws2 = ctx.raw_candidates(B)
+    for f in range(B):
+        assert np.array_equal(raws2[f], want[f][1]), "no-tap kernel: frame %d raw candidates" % f
+        assert np.array_equal(got2[f], want[f][0]), "no-tap kernel: frame %d boxes" % f
+    # and from device-resident frames through the asynchronous enqueue / wait pair, as bench.py feeds it
+    import torch
+    d = torch.from_numpy(frames).cuda()
+    ctx.enqueue_device(d.data_ptr(), B)
+    got3 = ctx.wait(B)
+    raws3 = ctx.raw_candidates(B)
+    for f in range(B):
+        assert np.array_equal(raws3[f], want[f][1]) and np.array_equal(got3[f], want[f][0]), "device input: frame %d" % f
 
 
 @pytest.mark.parametrize("name", ["alt2", "default", "alt_tree"])
@@ -86,6 +103,34 @@ def test_full_size_2160p_other_cascades(pkg, oracle, synth, name):
     grouped, raw = oc.detect(frame, 1.1, 2, (30, 30), (0, 0))
     assert np.array_equal(ctx.raw_candidates(1)[0], raw)
     assert np.array_equal(got[0], grouped) and len(grouped) >= 4
+
+
+def test_shared_prep_four_cascades_2160p(pkg, oracle, synth):
+    """BASELINE config #5 as ONE pass at its full size: the four cascades of data/ over one planted 3840x2160 frame
+    through hc_context_configure_shared (47-level union ladder; the prep route is whatever the cost model picks for
+    one 4K frame).  Raw candidates in canonical order and grouped boxes of every member against the oracle."""
+    names = ("alt", "alt2", "alt_tree", "default")
+    frame = synth.planted(2160, 3840, synth.frame_seed(5), nfaces=8, min_size=60, max_size=500)[0]
+    cascs = [pkg.Cascade(oracle.cascade_path(n)) for n in names]
+    ocs = [oracle.OracleCascade(oracle.cascade_path(n)) for n in names]
+    ctxs = [pkg.Context(c) for c in cascs]
+    pkg.configure_shared(ctxs, 2160, 3840, 1.1, 2, (30, 30), (0, 0), max_batch=1, cand_capacity=1 << 16)
+    assert len(ctxs[0].levels()) == 47
+    assert [sum(1 for L in c.levels() if L.nx > 0) for c in ctxs] == [45, 45, 45, 45]
+    assert [c.algorithmic_bytes() for c in ctxs] == [303677664, 303677664, 303677664, 440608352]      # SURVEY 8d
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        want = list(ex.map(lambda oc: oc.detect(frame, 1.1, 2, (30, 30), (0, 0)), ocs))
+    for c in ctxs:                                            # leader first, then every follower once
+        c.enqueue_host(frame[None])
+    total = 0
+    for c, (grouped, raw), name in zip(ctxs, want, names):
+        got = c.wait(1)
+        assert np.array_equal(c.raw_candidates(1)[0], raw), name
+        assert np.array_equal(got[0], grouped), name
+        total += len(grouped)
+    assert total >= 16
+    for c in ctxs:
+        c.close()
 
 
 def test_1080p_batch_two_cascades(pkg, oracle, synth):
@@ -168,9 +213,25 @@ def test_bench_two_ranks_on_one_gpu(pkg):
     ranks against the oracle before timing -- is the path of the 8-GPU run."""
     out = _run_bench(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "3", "--warmup", "1", "--batch", "20",
                       "--cpu-sample", "0"])
-    assert out["n_gpus"] == 2 and out["parity"]["bit_exact"] is True
+    assert out["parity"]["bit_exact"] is True
     assert out["parity"]["ranks_checked"] == 2 and out["parity"]["gathered_frames"] == 40
+    assert out["parity"]["frames_checked"] == 16
     assert out["value"] > 0 and out["config"]["frames_per_gpu_per_step"] == 20
+    # two ranks on one device is a rehearsal of the code path, not a scaling point: the line says so
+    assert out["n_gpus"] == 1 and out["ranks"] == 2 and out["rehearsal"] is True and "roofline" not in out
+    assert len(out["per_rank_fps"]) == 2 and "cpu_baseline" not in out
+
+
+def test_bench_five_ranks_rehearsal(pkg):
+    """The N = 8 code path with as many ranks as a one-GPU box admits: its process guard allows six processes on
+    the card, this pytest process is one of them, so five self-spawned ranks share the GPU (gloo transport).  Every
+    rank's frames come back through the gather and rank 0 checks frames of EVERY rank against the oracle."""
+    out = _run_bench(["--gpus", "5", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "16",
+                      "--cpu-sample", "4"])
+    assert out["parity"]["bit_exact"] is True and out["parity"]["ranks_checked"] == 5
+    assert out["parity"]["gathered_frames"] == 80 and out["parity"]["frames_checked"] == 15
+    assert out["ranks"] == 5 and out["rehearsal"] is True and len(out["per_rank_fps"]) == 5
+    assert out["cpu_baseline"]["value"] > 0            # reported by rank 0 at any N
 
 
 def test_bench_rccl_gather_single_rank(pkg):
@@ -178,7 +239,24 @@ def test_bench_rccl_gather_single_rank(pkg):
     communication stream with pinned staging (world size 1 is what a one-GPU box can give RCCL)."""
     out = _run_bench(["--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--batch", "20", "--cpu-sample", "0"])
     assert out["parity"]["bit_exact"] is True and out["parity"]["gathered_frames"] == 20
-    assert "RCCL" in out["config"]["parallelism"] and "roofline" in out
+    assert "RCCL" in out["config"]["parallelism"] and "roofline" in out and out["n_gpus"] == 1 and "rehearsal" not in out
+
+
+def test_bench_default_line_has_extra_configs(pkg):
+    """The driver's command (`python bench.py`, here with fewer steps): config #2 is `value`; configs #3 and #5 follow
+    outside its timed region under extra.configs, each with its own oracle check and roofline fraction; no process
+    group at N = 1 and the line says so."""
+    out = _run_bench(["--steps", "4", "--warmup", "1", "--extra-steps", "2", "--cpu-sample", "16"], timeout=1100)
+    assert out["n_gpus"] == 1 and out["parity"]["bit_exact"] is True and out["parity"]["frames_checked"] == 16
+    assert "no collective" in out["config"]["parallelism"] and "720p" in out["metric"]
+    assert out["roofline"]["kernel"] == "k_cascade" and 0 < out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    ex = out["extra"]["configs"]
+    assert sorted(ex) == ["3", "5"]
+    for k, nf in (("3", 96), ("5", 32)):
+        assert "error" not in ex[k], ex[k]
+        assert ex[k]["parity"]["bit_exact"] is True and ex[k]["frames_per_step"] == nf
+        assert ex[k]["value"] > 0 and 0 < ex[k]["roofline"]["frac"] < 1
 
 
 @pytest.mark.parametrize("min_neighbors", [2, 0])

@@ -81,3 +81,22 @@ def test_cv24_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
     got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
     want, _ = oracle.OracleCascade(oracle.cascade_path("alt_tree")).detect_cv24(frame, 1.1, 2, (30, 30))
     assert np.array_equal(got, want) and len(want) > 0
+
+
+def test_cv24_colour_input_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
+    """Legacy semantics with a colour image: 2.4's detectMultiScale converts BGR -> gray and then evaluates the legacy
+    path; the shim does the same (it used to fall through to the >= 4 evaluation without saying so)."""
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "shim_demo")
+    bgr, _ = synth.planted_bgr(240, 320, synth.frame_seed(2), nfaces=3, min_size=40, max_size=110)
+    f = tmp_path / "frame.bgr"
+    bgr.tofile(f)
+    oc = oracle.OracleCascade(oracle.cascade_path("alt"))
+    gray = oracle.bgr2gray(bgr)
+    want24, _ = oc.detect_cv24(gray, 1.1, 2, (30, 30))
+    want4, _ = oc.detect(gray, 1.1, 2, (30, 30))
+    for mode, want in (("legacy", want24), ("modern", want4)):
+        r = subprocess.run([demo, oracle.cascade_path("alt"), str(f), "240", "320", "1.1", mode, "3"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
+        assert np.array_equal(got, want) and len(want) > 0, mode
+    assert not np.array_equal(want24, want4)

@@ -298,17 +298,35 @@ def test_candidate_overflow_grows_and_reruns(pkg, oracle, synth):
         assert len(raw) > 4
         assert np.array_equal(got[f], want) and np.array_equal(raws[f], raw) and np.array_equal(again[f], want)
     _check_frame_all_taps(pkg, oracle, ctx, oc, frames[1], 1, 1.1, (30, 30))
-    # device-resident input takes the same route
+    # Caller-owned device frames (include/hip_cascade.h, hc_detect_batch_enqueue): stream-ordered recycling of the
+    # buffer is legal, so by default the library does NOT read it again -- the wait grows the workspace and reports
+    # HC_ERR_CAND_OVERFLOW; the caller enqueues the batch again and gets every rectangle.
     import torch
     d = torch.from_numpy(frames).cuda()
     torch.cuda.synchronize()
-    c2 = pkg.Context(casc)
+    want0 = [oc.detect(frames[f], 1.1, 0, (30, 30))[0] for f in range(3)]
+    st = torch.cuda.Stream()
+    c2 = pkg.Context(casc, stream=st.cuda_stream)
     c2.configure(240, 320, 1.1, 0, (30, 30), (0, 0), max_batch=3, cand_capacity=8)
-    c2.enqueue_device(d.data_ptr(), 3)
-    got0 = c2.wait(3)
+    with torch.cuda.stream(st):
+        c2.enqueue_device(d.data_ptr(), 3)
+        d.zero_()                                    # the decoder's next frames: ordered behind the batch's kernels on the same stream
+        with pytest.raises(pkg.HipCascadeError) as ei:
+            c2.wait(3)
+        assert ei.value.code == -8 and "enqueue the batch again" in str(ei.value)
+        d.copy_(torch.from_numpy(frames).cuda(), non_blocking=False)
+        c2.enqueue_device(d.data_ptr(), 3)           # the workspace has grown: this pass fits
+        got0 = c2.wait(3)
     for f in range(3):
-        want, _ = oc.detect(frames[f], 1.1, 0, (30, 30))
-        assert np.array_equal(got0[f], want)
+        assert np.array_equal(got0[f], want0[f])
+    # ... and with the caller's promise to keep the frames unmodified until the wait returns, the library re-runs by itself
+    c3 = pkg.Context(casc)
+    c3.configure(240, 320, 1.1, 0, (30, 30), (0, 0), max_batch=3, cand_capacity=8)
+    c3.set_rerun_on_overflow(True)
+    c3.enqueue_device(d.data_ptr(), 3)
+    got1 = c3.wait(3)
+    for f in range(3):
+        assert np.array_equal(got1[f], want0[f])
 
 
 def test_color_input_is_converted_like_upstream(pkg, oracle, synth):
@@ -757,3 +775,78 @@ def test_compiled_early_stages_and_generic_kernel_agree(pkg, oracle, synth, monk
         assert ctx.compiled_stages() == (want_n if spec == "1" else 0)
         for i in range(batch):
             assert np.array_equal(again[i], got[i])
+
+
+def test_sync_contexts_are_cached_per_geometry(pkg, oracle, synth):
+    """the synchronous drop-in call keeps a context per (geometry, call parameters), a few of them.  A
+    tracker that alternates between two scan sizes allocates nothing after the first call of each size, and the
+    alternating calls are as fast as calls that repeat one size (re-configuring used to cost ~20 hipMalloc per call)."""
+    import time
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    a = synth.planted(360, 640, synth.frame_seed(11), nfaces=4, min_size=40, max_size=120)[0]
+    b = synth.planted(720, 1280, synth.frame_seed(12))[0]
+    want = {id(a): oc.detect(a, 1.1, 2, (30, 30))[0], id(b): oc.detect(b, 1.1, 2, (30, 30))[0]}
+    for fr in (a, b):
+        assert np.array_equal(casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30)), want[id(fr)])
+    n0 = pkg.alloc_count()
+    assert n0 > 0
+    alt = {id(a): [], id(b): []}
+    for i in range(50):
+        fr = a if i % 2 == 0 else b
+        t0 = time.perf_counter()
+        got = casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30))
+        alt[id(fr)].append(time.perf_counter() - t0)
+        assert np.array_equal(got, want[id(fr)]), i
+    assert pkg.alloc_count() == n0, "alternating between two cached geometries must not allocate"
+    for fr in (a, b):
+        steady = []
+        for _ in range(25):
+            t0 = time.perf_counter()
+            casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30))
+            steady.append(time.perf_counter() - t0)
+        m_alt, m_steady = float(np.median(alt[id(fr)])), float(np.median(steady))
+        assert m_alt <= 1.2 * m_steady + 100e-6, "alternating %.3f ms vs steady %.3f ms" % (1e3 * m_alt, 1e3 * m_steady)
+    # other call parameters are another context; more combinations than the cache holds still give the right answers
+    for k, (rows, cols) in enumerate([(240, 320), (300, 400), (360, 480), (200, 260), (250, 330), (240, 320)]):
+        fr = synth.planted(rows, cols, synth.frame_seed(20 + k), nfaces=3, min_size=40, max_size=110)[0]
+        assert np.array_equal(casc.detect_multiscale(fr, 1.2, 3, 0, (24, 24)), oc.detect(fr, 1.2, 3, (24, 24))[0]), (rows, cols)
+    assert np.array_equal(casc.detect_multiscale(a, 1.1, 2, 0, (30, 30)), want[id(a)])
+
+
+def test_capacity_error_keeps_the_rectangles(pkg, oracle, synth, tmp_path):
+    """A too-small output buffer of a synchronous call: HC_ERR_CAPACITY, *out_count = the number found, and
+    hc_detect_multiscale_reread hands the kept rectangles over (no second detection).  Then the C++ shim on a frame
+    whose minNeighbors-0 output exceeds its first buffer of 1024."""
+    import ctypes as C
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    fr = synth.planted(240, 320, synth.frame_seed(31), nfaces=3, min_size=40, max_size=110)[0]
+    want, _ = oc.detect(fr, 1.1, 0, (30, 30))
+    assert len(want) > 8
+    small = np.zeros((2, 4), np.int32)
+    n = C.c_int()
+    rc = pkg.lib.hc_detect_multiscale(casc._h, fr.ctypes.data, 240, 320, fr.strides[0], 1.1, 0, 0, 30, 30, 0, 0, small.ctypes.data, 2, C.byref(n))
+    assert rc == -7 and n.value == len(want)
+    out = np.zeros((n.value, 4), np.int32)
+    m = C.c_int()
+    assert pkg.lib.hc_detect_multiscale_reread(casc._h, out.ctypes.data, n.value, C.byref(m)) == 0 and m.value == n.value
+    assert np.array_equal(out, want)
+    assert pkg.lib.hc_detect_multiscale_reread(casc._h, out.ctypes.data, n.value, C.byref(m)) == -9      # handed over once
+    # legacy call: same contract
+    want24, _ = oc.detect_cv24(fr, 1.1, 0, (30, 30))
+    rc = pkg.lib.hc_detect_multiscale_cv24(casc._h, fr.ctypes.data, 240, 320, fr.strides[0], 1.1, 0, 2, 30, 30, 0, 0, small.ctypes.data, 2, C.byref(n))
+    assert rc == -7 and n.value == len(want24)
+    out = np.zeros((n.value, 4), np.int32)
+    assert pkg.lib.hc_detect_multiscale_reread(casc._h, out.ctypes.data, n.value, C.byref(m)) == 0 and np.array_equal(out, want24)
+    # C++ shim
+    demo = os.path.join(os.path.dirname(pkg.LIB_PATH), "shim_demo")
+    big = synth.planted(720, 1280, synth.frame_seed(32), nfaces=70, min_size=40, max_size=90)[0]
+    wantb, _ = oc.detect(big, 1.1, 0, (30, 30))
+    assert len(wantb) > 1024, "stimulus no longer exceeds the shim's first buffer (%d)" % len(wantb)
+    f = tmp_path / "big.u8"
+    big.tofile(f)
+    r = subprocess.run([demo, path, str(f), "720", "1280", "1.1", "modern", "1", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
+    assert np.array_equal(got, wantb)

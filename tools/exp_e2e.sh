@@ -13,5 +13,5 @@ import numpy as np
 np.concatenate([fr] * 16).tofile("/tmp/frames720.u8")
 PY
 for pool in pageable registered pinned; do
-  timeout -k 10 200 ugproj-detector_amd/throughput_demo tests/golden/cascades/haarcascade_frontalface_alt.hcc /tmp/frames720.u8 256 720 1280 128 6 $pool | tail -1 || exit 1
+  timeout -k 10 200 ugproj-detector_amd/throughput_demo ugproj-detector_amd/data/cascades/haarcascade_frontalface_alt.hcc /tmp/frames720.u8 256 720 1280 128 6 $pool | tail -1 || exit 1
 done

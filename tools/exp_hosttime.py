@@ -4,7 +4,7 @@ import numpy as np, torch, importlib
 import bench
 pkg=bench.load_package(); synth=importlib.import_module("ugproj_detector_amd.synth"); shard=importlib.import_module("ugproj_detector_amd.shard")
 B=64
-casc=pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tests", "golden", "cascades", "haarcascade_frontalface_alt.hcc"))
+casc=pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "ugproj-detector_amd", "data", "cascades", "haarcascade_frontalface_alt.hcc"))
 fr=synth.make_frames('planted',16,720,1280); fr=fr[np.arange(B)%16]
 d=torch.from_numpy(fr).cuda(); torch.cuda.synchronize()
 ctx=pkg.Context(casc,0,torch.cuda.current_stream().cuda_stream); ctx.configure(720,1280,1.1,2,(30,30),(0,0),B,4096)

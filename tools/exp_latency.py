@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import bench, importlib
 pkg = bench.load_package(); synth = importlib.import_module("ugproj_detector_amd.synth")
-casc = pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tests", "golden", "cascades", "haarcascade_frontalface_alt.hcc"))
+casc = pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "ugproj-detector_amd", "data", "cascades", "haarcascade_frontalface_alt.hcc"))
 for (rows, cols) in [(360, 640), (720, 1280), (1080, 1920)]:
     fr = synth.planted(rows, cols, synth.frame_seed(0))[0]
     casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import bench, importlib
 pkg = bench.load_package(); synth = importlib.import_module("ugproj_detector_amd.synth")
-casc = pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tests", "golden", "cascades", "haarcascade_frontalface_alt.hcc"))
+casc = pkg.Cascade(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "ugproj-detector_amd", "data", "cascades", "haarcascade_frontalface_alt.hcc"))
 frames = synth.make_frames("planted", 16, 720, 1280)
 ctx = pkg.Context(casc)
 ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), 16, 1 << 14)

@@ -4,7 +4,7 @@
 difference a scalar constant.  The generic kernel forms each corner address with one VALU instruction and fetches the
 node records by scalar loads; here a stump needs neither ("compiled early stages").
 
-The input is a cascade in the package's own HCC1 container (tools/pack_cascade.py; tests/golden/cascades/*.hcc -- data, the
+The input is a cascade in the package's own HCC1 container (tools/pack_cascade.py; ugproj-detector_amd/data/cascades/*.hcc -- data, the
 same numbers as the XML).  The file records an FNV-1a hash of the model (hc_api.cpp model_hash walks the very same fields
 in the same order); the library takes the compiled stages only for a loaded cascade whose hash, window and tile
 geometry match, anything else runs the generic kernel.  Only stages whose f64 sum is exact in any order are compiled

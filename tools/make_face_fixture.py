@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates tests/golden/face64.u8: a 64x64 8-bit gray crop of the face in the
+"""Regenerates ugproj-detector_amd/data/face64.u8: a 64x64 8-bit gray crop of the face in the
 public-domain NASA astronaut portrait (Eileen Collins) that ships with scikit-image as
 skimage/data/astronaut.png.  Used only as an input stimulus for synthetic 'planted' frames
 (ugproj-detector_amd/synth.py); it is not an oracle and not part of the reference."""
@@ -15,5 +15,5 @@ x, y, s = 176, 65, 98
 m = 12
 box = (x - m, y - m, x + s + m, y + s + m)
 face = im.crop(box).resize((64, 64), Image.BOX)
-np.asarray(face, np.uint8).tofile("tests/golden/face64.u8")
-print("wrote tests/golden/face64.u8", np.asarray(face).mean())
+np.asarray(face, np.uint8).tofile("ugproj-detector_amd/data/face64.u8")
+print("wrote ugproj-detector_amd/data/face64.u8", np.asarray(face).mean())

@@ -2,7 +2,7 @@ import sys, struct, numpy as np
 sys.path.insert(0,'/root/repo/tests')
 import conftest
 pkg = conftest.load_package()
-c = pkg.Cascade('/root/repo/tests/golden/cascades/haarcascade_frontalface_alt.hcc')
+c = pkg.Cascade('/root/repo/ugproj-detector_amd/data/cascades/haarcascade_frontalface_alt.hcc')
 st, sn, tn, nr, nt, nl, nrr, lf = c.dump()
 nr = nr.reshape(-1, 15)
 def fhex(x): return "__uint_as_float(0x%08xu)" % struct.unpack('<I', struct.pack('<f', float(x)))[0]

@@ -28,6 +28,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HC_LIB_PATH: A/B experiments with alternative builds of the same library (tools/exp_*.sh); never a different backend
 LIB_PATH = os.environ.get("HC_LIB_PATH") or os.path.join(_HERE, "libhip_cascade.so")
 
+DATA_DIR = os.path.join(_HERE, "data")
+CASCADE_NAMES = ("alt", "alt2", "alt_tree", "default")
+
+
+def cascade_path(name):
+    """packed parameters of reference data/haarcascade_frontalface_<name>.xml that ship with the package"""
+    if name not in CASCADE_NAMES:
+        raise ValueError("unknown stock cascade %r (one of %s); pass a path to Cascade() for any other file" % (name, ", ".join(CASCADE_NAMES)))
+    return os.path.join(DATA_DIR, "cascades", "haarcascade_frontalface_%s.hcc" % name)
+
+
 HC_NKERNELS = 5
 TAP_PYRAMID, TAP_SUM, TAP_SQSUM, TAP_VNF, TAP_STAGES, TAP_FACE_MASK, TAP_FACE_GRAY, TAP_FACE_BGR = range(8)
 SKIN_LOWER, SKIN_UPPER = (0, 133, 77), (255, 173, 127)      # reference src/structure.cc:75-82 defaults
@@ -71,6 +82,9 @@ _SIGS = {
     "hc_detect_multiscale_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                              C.POINTER(C.c_int)]),
+    "hc_detect_multiscale_reread": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "hc_debug_alloc_count": (C.c_longlong, []),
+    "hc_context_set_rerun_on_overflow": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_convert_bgr2gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]),
     "hc_boxes_save": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_boxes_load": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
@@ -291,6 +305,10 @@ class Context:
         _check(lib.hc_detect_batch_enqueue(self._h, C.c_void_p(dptr), frame_stride or self.rows * self.cols,
                                            row_step or self.cols, nframes))
 
+    def set_rerun_on_overflow(self, allow=True):
+        """caller-owned device frames stay valid and unmodified until wait(): a candidate-workspace overflow re-runs by itself"""
+        _check(lib.hc_context_set_rerun_on_overflow(self._h, int(allow)))
+
     def enqueue_host(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)
         assert frames.ndim == 3 and frames.shape[1:] == (self.rows, self.cols)
@@ -372,6 +390,11 @@ class Context:
         if a.size:
             _check(lib.hc_context_read_tap(self._h, frame, level_index, what, a.ctypes.data, a.nbytes))
         return a
+
+
+def alloc_count():
+    """device / pinned-host allocations the library has made in this process (hc_debug_alloc_count)"""
+    return int(lib.hc_debug_alloc_count())
 
 
 def configure_shared(contexts, rows, cols, scale_factor=1.1, min_neighbors=3, min_size=(0, 0), max_size=(0, 0), max_batch=1,

@@ -44,10 +44,13 @@ int set_err(int code, const std::string& what) { g_err = what; return code; }
 const char* const kKernelNames[HC_NKERNELS] = {"k_pyramid_integral", "k_integral_rows", "k_integral_cols", "k_variance",
                                                "k_cascade"};
 
+std::atomic<long long> g_alloc_count{0};
+
 template <class T>
 int dev_alloc(T** p, size_t n) {
   *p = nullptr;
   if (n == 0) n = 1;
+  g_alloc_count++;
   hipError_t e = hipMalloc((void**)p, n * sizeof(T));
   if (e != hipSuccess) return set_err(HC_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   return HC_OK;
@@ -119,6 +122,19 @@ class WorkerPool {
 
 namespace hc {
 int set_error(int code, const std::string& what) { return set_err(code, what); }   // for the other translation units
+void count_alloc() { g_alloc_count++; }
+int deliver_sync_result(hc_cascade* c, const std::vector<hc_rect>& boxes, hc_rect* out, int out_capacity, int* out_count) {
+  c->last_result_valid = false;
+  *out_count = (int)boxes.size();
+  if ((int)boxes.size() > out_capacity || (!out && !boxes.empty())) {
+    c->last_result = boxes;            // the detection is done: the caller re-reads it instead of running it again
+    c->last_result_valid = true;
+    return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small (*out_count holds the size needed; "
+                                    "hc_detect_multiscale_reread returns the rectangles without running the detection again)");
+  }
+  for (size_t i = 0; i < boxes.size(); i++) out[i] = boxes[i];
+  return HC_OK;
+}
 }
 
 struct hc_context {
@@ -222,6 +238,11 @@ struct hc_context {
   // candidate workspace (the caller keeps its frames valid until the wait returns)
   const uint8_t* inflight_src = nullptr;
   size_t inflight_frame_stride = 0, inflight_row_step = 0;
+  // Re-running needs the frames as they were at the enqueue.  Staging planes of the context (host input, colour input,
+  // the detectFaces gray plane) always qualify; a caller-owned device buffer only when the caller has promised to
+  // keep it unmodified until the wait returns (hc_context_set_rerun_on_overflow).
+  bool rerun_caller_frames = false;
+  const void* prep_src = nullptr;        // leader of a shared pass: the frame pointer its caller passed for the current batch
   bool taps_enabled = false, timing_enabled = false, timed_last = false;
   hipEvent_t ev[HC_NKERNELS + 1] = {};
   float last_ms[HC_NKERNELS] = {};
@@ -566,15 +587,22 @@ hc_level to_public(const hc::DevLevel& L) {
 }
 
 // A group that shares one prep pass is enqueued leader first, then every follower once, with the same batch.
-int shared_enqueue_check(hc_context* c, int nframes) {
+int shared_enqueue_check(hc_context* c, const void* frames, int nframes) {
   if (c->leader) {
     hc_context* L = c->leader;
     if (L->prep_seq == c->seen_seq) return set_err(HC_ERR_STATE, "shared prep: enqueue the leader's batch first (once per follower scan)");
     if (L->prep_frames != nframes) return set_err(HC_ERR_ARG, "shared prep: follower batch size differs from the leader's");
+    // A follower scans whatever the leader's LAST prep pass left in the integrals.  A leader that was enqueued again
+    // before this follower scanned the previous batch would make it silently return the newer batch's rectangles for
+    // the older frames: the frame pointer names the batch, so a follower enqueued with another one is refused.
+    if (L->prep_src != frames)
+      return set_err(HC_ERR_STATE, "shared prep: the follower was enqueued with a batch other than the leader's current one "
+                                   "(per batch: the leader first, then every follower with the same frame pointer)");
     c->seen_seq = L->prep_seq;
   } else if (!c->followers.empty()) {
     c->prep_seq++;
     c->prep_frames = nframes;
+    c->prep_src = frames;
   }
   return HC_OK;
 }
@@ -744,7 +772,7 @@ int hc_cascade_load(const char* path, hc_cascade** out) {
 
 void hc_cascade_free(hc_cascade* c) {
   if (!c) return;
-  if (c->default_ctx) hc_context_destroy(c->default_ctx);
+  for (hc_context* ctx : c->sync_ctxs) hc_context_destroy(ctx);
   delete c;
 }
 
@@ -938,6 +966,7 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
     ctx->n_seg_items[k] = (int)seg.size();
     if ((rc = dev_upload(&ctx->d_seg_items[k], seg))) return rc;
   }
+  g_alloc_count += 2;
   HIPCHK(hipHostMalloc((void**)&ctx->h_cand, ctx->cand_cap * sizeof(unsigned long long), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
   ctx->pending = 0;
@@ -985,7 +1014,7 @@ int hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t fra
   if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
-  if (int rc = shared_enqueue_check(ctx, nframes)) return rc;
+  if (int rc = shared_enqueue_check(ctx, d_frames, nframes)) return rc;
   return enqueue_device(ctx, d_frames, frame_stride_bytes, row_step_bytes, nframes);
 }
 
@@ -996,7 +1025,7 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   if (row_step_bytes < (size_t)ctx->plan.cols) return set_err(HC_ERR_ARG, "row step smaller than the row");
   if (ctx->pending) return set_err(HC_ERR_STATE, "previous batch not waited");
   HIPCHK(hipSetDevice(ctx->device));
-  if (int rc = shared_enqueue_check(ctx, nframes)) return rc;
+  if (int rc = shared_enqueue_check(ctx, h_frames, nframes)) return rc;
   if (ctx->leader) return enqueue_device(ctx, h_frames, frame_stride_bytes, row_step_bytes, nframes);   // frames went up with the leader
   if (int rc = ensure_frames(ctx)) return rc;
   const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
@@ -1053,15 +1082,23 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
       return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow and the batch cannot be re-run "
                                            "(shared prep: the leader has already moved on); raise cand_capacity");
     const size_t want = (size_t)count + (size_t)count / 4 + 1024;
+    // the frames of a follower are the leader's integrals, still in place (checked above)
+    const bool own_frames = ctx->leader || ctx->inflight_src == ctx->d_frames || ctx->inflight_src == ctx->d_gray;
+    const bool may_rerun = own_frames || ctx->rerun_caller_frames;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->d_cand); ctx->d_cand = nullptr;
     (void)hipHostFree(ctx->h_cand); ctx->h_cand = nullptr;
     ctx->cand_cap = 0;
     int rc = dev_alloc(&ctx->d_cand, want);
     if (rc) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing it failed: " + g_err);
+    g_alloc_count++;
     if (hipHostMalloc((void**)&ctx->h_cand, want * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
       return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing the host buffer failed");
     ctx->cand_cap = want;
+    if (!may_rerun)
+      return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow: " + std::to_string(count) + " candidates; the workspace "
+                                           "now holds " + std::to_string(want) + " -- enqueue the batch again (caller-owned device "
+                                           "frames are only re-read by the library after hc_context_set_rerun_on_overflow(ctx, 1))");
     if ((rc = enqueue_device(ctx, ctx->inflight_src, ctx->inflight_frame_stride, ctx->inflight_row_step, nframes))) return rc;
     ctx->pending = 0;
   }
@@ -1177,6 +1214,7 @@ int hc_context_enable_faces(hc_context* ctx) {
   ctx->n_mask_items[0] = (int)ri.size(); ctx->n_mask_items[1] = (int)ci.size();
   if ((rc = dev_upload(&ctx->d_mask_items[0], ri))) return rc;
   if ((rc = dev_upload(&ctx->d_mask_items[1], ci))) return rc;
+  g_alloc_count += 2;
   HIPCHK(hipHostMalloc((void**)&ctx->h_boxes, (size_t)ctx->box_cap * 5 * sizeof(int), hipHostMallocDefault));
   HIPCHK(hipHostMalloc((void**)&ctx->h_boxsums, (size_t)ctx->box_cap * sizeof(uint32_t), hipHostMallocDefault));
   ctx->faces_enabled = true;
@@ -1275,12 +1313,9 @@ int hc_faces_batch_enqueue_host(hc_context* ctx, const uint8_t* h_bgr, size_t fr
   return faces_enqueue(ctx, stage, rows * rowb, rowb, nframes, lower, upper);
 }
 
-int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
-  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+static int faces_wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   if (!ctx->pending || !ctx->faces_pending) return set_err(HC_ERR_STATE, "no detectFaces batch enqueued");
-  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
   ctx->faces_pending = false;
-  std::vector<std::vector<hc_rect>> grouped;
   int rc = wait_core(ctx, grouped);
   if (rc != HC_OK) return rc;
   // skin post-filter (detector.cc:33-42): m = norm(mean(mask(roi))); keep iff !(m/256 < 0.8)
@@ -1310,6 +1345,15 @@ int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t
     }
     g.swap(keep);
   }
+  return HC_OK;
+}
+
+int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
+  if (!ctx || !ctx->configured) return set_err(HC_ERR_STATE, "context not configured");
+  if (!offsets || (!out && out_capacity > 0)) return set_err(HC_ERR_ARG, "null output");
+  std::vector<std::vector<hc_rect>> grouped;
+  int rc = faces_wait_core(ctx, grouped);
+  if (rc != HC_OK) return rc;
   return emit(grouped, out, out_capacity, offsets);
 }
 
@@ -1332,10 +1376,9 @@ int hc_detect_faces(hc_cascade* c, const uint8_t* bgr, int rows, int cols, size_
   if (rc) return rc;
   if ((rc = hc_context_enable_faces(ctx))) return rc;
   if ((rc = hc_faces_batch_enqueue_host(ctx, bgr, 0, step_bytes, 1, lower, upper))) return rc;
-  int32_t ofs[2] = {0, 0};
-  if ((rc = hc_faces_batch_wait(ctx, out, out_capacity, ofs))) return rc;
-  *out_count = ofs[1];
-  return HC_OK;
+  std::vector<std::vector<hc_rect>> grouped;
+  if ((rc = faces_wait_core(ctx, grouped))) return rc;
+  return hc::deliver_sync_result(c, grouped[0], out, out_capacity, out_count);
 }
 
 int hc_batch_raw_candidates(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
@@ -1477,20 +1520,37 @@ int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
   HIPCHK(hipGetDevice(&dev));
-  hc_context* ctx = c->default_ctx;
-  if (ctx && ctx->device != dev) { hc_context_destroy(ctx); ctx = c->default_ctx = nullptr; }
-  int rc;
-  if (!ctx) {
-    if ((rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
-    c->default_ctx = ctx;
-  }
-  const hc::Plan& P = ctx->plan;
+  c->last_result_valid = false;
   const int emw = (max_w == 0 || max_h == 0) ? cols : max_w, emh = (max_w == 0 || max_h == 0) ? rows : max_h;
-  if (!ctx->configured || P.rows != rows || P.cols != cols || P.scale_factor != scale_factor || P.min_w != min_w ||
-      P.min_h != min_h || P.max_w != emw || P.max_h != emh || ctx->min_neighbors != min_neighbors) {
-    if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, 1, 1 << 16)))
-      return rc;
+  auto& lru = c->sync_ctxs;                    // most recently used first
+  for (size_t i = 0; i < lru.size(); i++) {
+    hc_context* x = lru[i];
+    const hc::Plan& P = x->plan;
+    if (x->device == dev && x->configured && P.rows == rows && P.cols == cols && P.scale_factor == scale_factor &&
+        P.min_w == min_w && P.min_h == min_h && P.max_w == emw && P.max_h == emh && x->min_neighbors == min_neighbors) {
+      std::rotate(lru.begin(), lru.begin() + i, lru.begin() + i + 1);
+      *out = x;
+      return HC_OK;
+    }
   }
+  // a combination not seen lately: a new context while the cache has room, else the least recently used one re-configured
+  static const size_t cache_size = [] {
+    const char* e = getenv("HC_SYNC_CONTEXTS");
+    return (size_t)std::min(64, std::max(1, e ? atoi(e) : 4));
+  }();
+  hc_context* ctx = nullptr;
+  int rc;
+  if (lru.size() >= cache_size) {
+    ctx = lru.back();
+    lru.pop_back();
+    if (ctx->device != dev) { hc_context_destroy(ctx); ctx = nullptr; }
+  }
+  if (!ctx && (rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
+  if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, 1, 1 << 16))) {
+    hc_context_destroy(ctx);
+    return rc;
+  }
+  lru.insert(lru.begin(), ctx);
   *out = ctx;
   return HC_OK;
 }
@@ -1544,9 +1604,28 @@ int hc_detect_multiscale_image(hc_cascade* c, const uint8_t* image, int rows, in
     if ((rc = stage_color_as_gray(ctx, image, rows, cols, channels, step_bytes))) return rc;
     if ((rc = enqueue_device(ctx, ctx->d_frames, (size_t)rows * cols, cols, 1))) return rc;
   }
-  int32_t ofs[2] = {0, 0};
-  if ((rc = hc_detect_batch_wait(ctx, out, out_capacity, ofs))) return rc;
-  *out_count = ofs[1];
+  std::vector<std::vector<hc_rect>> grouped;
+  if ((rc = wait_core(ctx, grouped))) return rc;
+  return hc::deliver_sync_result(c, grouped[0], out, out_capacity, out_count);
+}
+
+int hc_detect_multiscale_reread(hc_cascade* c, hc_rect* out, int out_capacity, int* out_count) {
+  if (!c || !out_count) return set_err(HC_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> lock(c->mu);
+  if (!c->last_result_valid) return set_err(HC_ERR_STATE, "the last synchronous call on this cascade did not end in HC_ERR_CAPACITY");
+  *out_count = (int)c->last_result.size();
+  if ((int)c->last_result.size() > out_capacity || !out) return set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
+  for (size_t i = 0; i < c->last_result.size(); i++) out[i] = c->last_result[i];
+  c->last_result_valid = false;
+  c->last_result.clear();
+  return HC_OK;
+}
+
+long long hc_debug_alloc_count(void) { return g_alloc_count.load(); }
+
+int hc_context_set_rerun_on_overflow(hc_context* ctx, int allow) {
+  if (!ctx) return set_err(HC_ERR_ARG, "null context");
+  ctx->rerun_caller_frames = allow != 0;
   return HC_OK;
 }
 

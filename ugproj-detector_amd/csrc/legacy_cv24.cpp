@@ -163,7 +163,8 @@ int detect24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step
     return set_error(HC_ERR_HIP, "legacy mode: device allocation / upload failed");
   hipStream_t st = nullptr;
   std::vector<unsigned long long> keys;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  bool done = false;
+  for (int attempt = 0; attempt < 3 && !done; attempt++) {
     DevBuf<unsigned long long> cand;
     if (cand.alloc(cand_cap)) return set_error(HC_ERR_HIP, "legacy mode: candidate buffer allocation failed");
     hipError_t e = hipMemcpy2DAsync(d_img.p, cols, gray, step, cols, rows, hipMemcpyHostToDevice, st);
@@ -188,8 +189,9 @@ int detect24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step
       return set_error(HC_ERR_HIP, "legacy mode: candidate copy failed");
     if (taps && grid && hipMemcpy(taps, d_taps.p, (size_t)grid, hipMemcpyDeviceToHost) != hipSuccess)
       return set_error(HC_ERR_HIP, "legacy mode: tap copy failed");
-    break;
+    done = true;
   }
+  if (!done) return set_error(HC_ERR_CAND_OVERFLOW, "legacy mode: raw candidate workspace overflow after growing it twice");
   std::sort(keys.begin(), keys.end());            // level -> y -> x: the single-thread order of upstream's loops
   for (unsigned long long k : keys) {
     const Level24& L = lv[(size_t)(k >> 32)];
@@ -226,10 +228,7 @@ int hc_detect_multiscale_cv24_taps(hc_cascade* c, const uint8_t* gray, int rows,
   std::vector<hc_rect> boxes;
   int rc = detect24(c, gray, rows, cols, step_bytes, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, boxes, taps, taps_capacity);
   if (rc != HC_OK) return rc;
-  if ((int)boxes.size() > out_capacity || (!out && !boxes.empty())) return set_error(HC_ERR_CAPACITY, "output rectangle buffer too small");
-  for (size_t i = 0; i < boxes.size(); i++) out[i] = boxes[i];
-  *out_count = (int)boxes.size();
-  return HC_OK;
+  return hc::deliver_sync_result(c, boxes, out, out_capacity, out_count);
 }
 
 int hc_detect_multiscale_cv24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,

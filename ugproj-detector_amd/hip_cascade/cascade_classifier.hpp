@@ -96,8 +96,8 @@ class CascadeClassifier {
 
   // Explicit switch to the OpenCV 2.4.x evaluation the reference was written against (see
   // hc_detect_multiscale_cv24 in include/hip_cascade.h).  Off by default: the backend follows OpenCV >= 4.  With it on,
-  // detectMultiScale needs the CASCADE_SCALE_IMAGE flag (the reference passes it, src/tracker/detector.cc:30) and a
-  // 1-channel image.
+  // detectMultiScale needs the CASCADE_SCALE_IMAGE flag (the reference passes it, src/tracker/detector.cc:30); a colour
+  // image is converted with cvtColor(.., BGR2GRAY) first, as 2.4's detectMultiScale does.
   void setLegacySemantics(bool on) { legacy_ = on; }
   bool legacySemantics() const { return legacy_; }
 
@@ -110,27 +110,37 @@ class CascadeClassifier {
     const int ch = mat_u8_channels(image);
     if (!(scaleFactor > 1.0) || (ch != 1 && ch != 3 && ch != 4) || !mat_data(image))
       throw std::invalid_argument("hip_cascade::detectMultiScale: scaleFactor > 1 and an 8-bit image with 1, 3 or 4 channels required");
-    int cap = 1024;
-    for (;;) {
-      objects.resize(cap);
-      int n = 0;
-      const int rc = legacy_ && ch == 1
-                         ? hc_detect_multiscale_cv24(h_, mat_data(image), mat_rows(image), mat_cols(image), mat_step(image),
-                                                     scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
-                                                     maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
-                                                     cap, &n)
-                         : hc_detect_multiscale_image(h_, mat_data(image), mat_rows(image), mat_cols(image), ch, mat_step(image),
-                                                      scaleFactor, minNeighbors, flags, minSize.width, minSize.height,
-                                                      maxSize.width, maxSize.height, reinterpret_cast<hc_rect*>(objects.data()),
-                                                      cap, &n);
-      if (rc == HC_ERR_CAPACITY && cap < (1 << 22)) { cap *= 4; continue; }
-      if (rc != HC_OK) {
-        objects.clear();
+    const unsigned char* data = mat_data(image);
+    size_t step = mat_step(image);
+    int nch = ch;
+    std::vector<unsigned char> gray;
+    if (legacy_ && ch != 1) {
+      // 2.4: cvtColor(image, gray, CV_BGR2GRAY), then the legacy evaluation of the gray plane
+      gray.resize((size_t)mat_rows(image) * mat_cols(image));
+      if (hc_convert_bgr2gray(data, mat_rows(image), mat_cols(image), ch, step, gray.data(), (size_t)mat_cols(image)) != HC_OK)
         throw std::runtime_error(std::string("hip_cascade::detectMultiScale: ") + hc_last_error());
-      }
-      objects.resize(n);
-      return;
+      data = gray.data();
+      step = (size_t)mat_cols(image);
+      nch = 1;
     }
+    objects.resize(1024);
+    int n = 0;
+    int rc = legacy_ ? hc_detect_multiscale_cv24(h_, data, mat_rows(image), mat_cols(image), step, scaleFactor, minNeighbors, flags,
+                                                 minSize.width, minSize.height, maxSize.width, maxSize.height,
+                                                 reinterpret_cast<hc_rect*>(objects.data()), (int)objects.size(), &n)
+                     : hc_detect_multiscale_image(h_, data, mat_rows(image), mat_cols(image), nch, step, scaleFactor, minNeighbors,
+                                                  flags, minSize.width, minSize.height, maxSize.width, maxSize.height,
+                                                  reinterpret_cast<hc_rect*>(objects.data()), (int)objects.size(), &n);
+    if (rc == HC_ERR_CAPACITY) {
+      // more rectangles than the first buffer holds: the detection is done, the library kept them (*out_count = how many)
+      objects.resize(n);
+      rc = hc_detect_multiscale_reread(h_, reinterpret_cast<hc_rect*>(objects.data()), n, &n);
+    }
+    if (rc != HC_OK) {
+      objects.clear();
+      throw std::runtime_error(std::string("hip_cascade::detectMultiScale: ") + hc_last_error());
+    }
+    objects.resize(n);
   }
 
   hc_cascade* handle() const { return h_; }   // for hip_cascade::FaceDetector

@@ -37,18 +37,18 @@ class FaceDetector {
     int lower[3], upper[3];
     for (int k = 0; k < 3; k++) { lower[k] = (int)cfg_.skin_lower[k]; upper[k] = (int)cfg_.skin_upper[k]; }
     std::vector<hc_rect> buf(1024);
-    for (;;) {
-      int n = 0;
-      const int rc = hc_detect_faces(cascade.handle(), mat_data(frame), mat_rows(frame), mat_cols(frame), mat_step(frame),
-                                     lower, upper, cfg_.scale, buf.data(), (int)buf.size(), &n);
-      if (rc == HC_ERR_CAPACITY && buf.size() < (1u << 22)) { buf.resize(buf.size() * 4); continue; }
-      if (rc != HC_OK) throw std::runtime_error(std::string("hip_cascade::FaceDetector::detectFaces: ") + hc_last_error());
-      for (int i = 0; i < n; i++) {
-        Rect r;
-        r.x = buf[i].x; r.y = buf[i].y; r.width = buf[i].width; r.height = buf[i].height;
-        rects.push_back(r);                       // the reference appends (detector.cc:41)
-      }
-      return;
+    int n = 0;
+    int rc = hc_detect_faces(cascade.handle(), mat_data(frame), mat_rows(frame), mat_cols(frame), mat_step(frame), lower, upper,
+                             cfg_.scale, buf.data(), (int)buf.size(), &n);
+    if (rc == HC_ERR_CAPACITY) {                  // the library kept the rectangles: no second detection
+      buf.resize(n);
+      rc = hc_detect_multiscale_reread(cascade.handle(), buf.data(), n, &n);
+    }
+    if (rc != HC_OK) throw std::runtime_error(std::string("hip_cascade::FaceDetector::detectFaces: ") + hc_last_error());
+    for (int i = 0; i < n; i++) {
+      Rect r;
+      r.x = buf[i].x; r.y = buf[i].y; r.width = buf[i].width; r.height = buf[i].height;
+      rects.push_back(r);                         // the reference appends (detector.cc:41)
     }
   }
 

@@ -2,8 +2,9 @@
 // tracker uses cv::CascadeClassifier: load() once (src/file_io.cc:11), then
 // detectMultiScale(gray, faces, scale, 2, 0|CASCADE_SCALE_IMAGE, Size(30,30)) per frame
 // (src/tracker/detector.cc:25-31).  Input: a raw 8-bit gray frame file.
-//   shim_demo <cascade.xml|.hcc> <frame.u8> <rows> <cols> [scale=1.1] [legacy]
-// A sixth argument "legacy" switches the classifier to the OpenCV 2.4.x evaluation (setLegacySemantics).
+//   shim_demo <cascade.xml|.hcc> <frame.u8> <rows> <cols> [scale=1.1] [legacy|modern] [channels=1] [minNeighbors=2]
+// A sixth argument "legacy" switches the classifier to the OpenCV 2.4.x evaluation (setLegacySemantics); channels 3 / 4
+// reads a packed BGR / BGRA frame, which detectMultiScale converts itself as upstream does.
 // Output: one "x y w h" line per detected face; exit code 0 on success, 1 on load failure
 // (the reference's convention), 2 on a detection error.
 #include <cstdio>
@@ -49,14 +50,15 @@ int main(int argc, char** argv) {
   const int rows = atoi(argv[3]), cols = atoi(argv[4]);
   const double scale = argc > 5 ? atof(argv[5]) : 1.1;
   if (argc > 6 && !strcmp(argv[6], "legacy")) cascade.setLegacySemantics(true);
-  std::vector<unsigned char> buf((size_t)rows * cols);
+  const int channels = argc > 7 ? atoi(argv[7]) : 1, min_neighbors = argc > 8 ? atoi(argv[8]) : 2;
+  std::vector<unsigned char> buf((size_t)rows * cols * channels);
   FILE* f = fopen(argv[2], "rb");
   if (!f || fread(buf.data(), 1, buf.size(), f) != buf.size()) { fprintf(stderr, "cannot read frame\n"); return 1; }
   fclose(f);
-  hip_cascade::Mat gray(rows, cols, buf.data());
+  hip_cascade::Mat gray(rows, cols, buf.data(), 0, channels);
   std::vector<hip_cascade::Rect> facesInGray;
   try {
-    cascade.detectMultiScale(gray, facesInGray, scale, 2, 0 | hip_cascade::CASCADE_SCALE_IMAGE, hip_cascade::Size(30, 30));
+    cascade.detectMultiScale(gray, facesInGray, scale, min_neighbors, 0 | hip_cascade::CASCADE_SCALE_IMAGE, hip_cascade::Size(30, 30));
   } catch (const std::exception& e) {
     fprintf(stderr, "%s\n", e.what());
     return 2;

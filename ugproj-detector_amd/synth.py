@@ -9,8 +9,8 @@ every machine.  PRNG: SplitMix64, frame i seeded with 0x9E3779B97F4A7C15 * (i + 
   S3 "planted"  S2 + P face patches per frame stamped at SplitMix-chosen places and sizes
                 (non-empty detections; every kernel and the grouping are exercised)
 
-The face patch is tests/golden/face64.u8: a 64x64 gray crop of the public-domain NASA
-portrait shipped with scikit-image (`astronaut.png`), see tests/golden/README.md.  It is an
+The face patch is data/face64.u8: a 64x64 gray crop of the public-domain NASA
+portrait shipped with scikit-image (`astronaut.png`), see data/README.md.  It is an
 input stimulus, not an oracle.
 """
 import os
@@ -73,7 +73,7 @@ def texture(rows, cols, seed):
 def face_patch():
     global _FACE
     if _FACE is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "face64.u8")
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "face64.u8")
         _FACE = np.fromfile(path, np.uint8).reshape(64, 64)
     return _FACE
 
