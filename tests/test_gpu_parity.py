@@ -5,6 +5,9 @@ stage-pass counts, raw candidates in canonical order, grouped boxes.
 Integer/byte/index work: exact equality.  The only floating-point tap (vnf, f32) is also
 compared for exact bit equality (tolerance 0): the path is defined by its IEEE operation order.
 """
+import os
+import subprocess
+
 import numpy as np
 import pytest
 

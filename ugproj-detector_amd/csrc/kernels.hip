@@ -3,7 +3,7 @@
 // The path replaces what cv::CascadeClassifier::detectMultiScale does per frame for the
 // reference's call at src/tracker/detector.cc:25-31 (semantics: SURVEY.md Appendix A):
 //   k_resize         A.4  exact bilinear pyramid, every level from the original frame
-//   k_integral_rows  A.5  row prefix sums (sum, sqsum) -- wave64 __shfl_up scan + carry
+//   k_integral_rows  A.5  row prefix sums (sum, sqsum) -- wave64 DPP scan (row_shr / row_bcast) + register carry
 //   k_integral_cols  A.5  column prefix sums, coalesced across lanes
 //   k_variance       A.6a setWindow: variance normalisation factor + evaluable gate
 //   k_cascade        A.6b/A.7/A.8/A.9 stage evaluation from LDS-staged integral tiles,
@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 #include "device_types.h"
 #include "kernels.h"
@@ -199,8 +200,53 @@ constexpr int PI_THREADS = HC_PI_THREADS;   // 8 (16) wavefronts: one pyramid ro
 constexpr int PI_UNROLL = 4;      // consecutive pixels per lane in phase 1 (one 16-byte LDS access per quantity)
 static_assert(PI_UNROLL == 4, "phase 1 moves four pixels per lane as one uint4");
 
-template <int CMAX>   // columns per thread: level width <= PI_THREADS * CMAX
-__global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
+// ---- variance factors from row prefixes that are still in LDS (k_pyramid_integral, NH > 0) ----
+// The inner rect of a window spans norm_h pixel rows; its sums are  S = sum over those rows of B(r),  B(r) = the
+// norm_w-pixel box sum of row r = rp(r, x + norm_w) - rp(r, x)  with rp the row prefix the chunk's phase 1 left in LDS.
+// Every thread owns up to two grid columns and slides S down the level: S += B(r) - B(r - norm_h).  The norm_h old
+// box sums live in a register ring of VR_RING entries, indexed with compile-time constants (the chunk loop is
+// dispatched on y0 mod VR_RING), one packed word per row: B of the pixels (<= 32 * 255 < 2^13) in the low bits and
+// 255 * B - Bsq = sum p (255 - p) (<= 32 * 16256 < 2^19) above them.  Nothing is read back from the integrals in
+// global memory (the old phase 3 fetched 8 words per window from rows this workgroup had written norm_h rows earlier:
+// 8.3 GB per 256 frames, none of it found in L2 any more).
+constexpr int VR_RING = 24;       // > norm_h (18 or 22), a multiple of the chunk height 8
+constexpr int VR_COLS = 1;        // grid columns per thread: the first PI_THREADS columns of a level (the few beyond them,
+                                  // two levels of a 720p ladder, take the read-back route below: 24 registers per column)
+struct VarRing {
+  uint32_t pk[VR_COLS][VR_RING];
+  uint32_t ws[VR_COLS], wq[VR_COLS];
+};
+
+template <int NH, int PH, int R0>   // PH = (y0 / 8) mod 3: the ring slot of the chunk's row r is PH * 8 + r; rows R0 .. 7
+__device__ __forceinline__ void variance_rows(VarRing& V, const uint32_t* rs, const uint32_t* rq, int lds_pitch, int nr, int y0,
+                                              int ys, int gnx, int gny, int nw, double area, float* __restrict__ vout) {
+  static_assert(NH > 0 && NH < VR_RING, "ring must be longer than the inner rect is tall");
+  if constexpr (R0 < 8) {
+    if (R0 >= nr) return;                                    // uniform
+    const int yt = y0 + R0 - NH;                             // origin row of the windows whose inner rect ends in row y0 + R0
+    const int gy = ys == 1 ? yt : (yt >> 1);
+    const bool emit = yt >= 0 && (ys == 1 || !(yt & 1)) && gy < gny;   // uniform
+    constexpr int slot_w = (PH * 8 + R0) % VR_RING, slot_r = (PH * 8 + R0 + VR_RING - NH) % VR_RING;
+#pragma unroll
+    for (int k = 0; k < VR_COLS; k++) {
+      const int gx = (int)threadIdx.x + k * PI_THREADS;
+      if (gx < gnx) {
+        const int xo = R0 * lds_pitch + gx * ys;
+        const uint32_t bs = rs[xo + nw] - rs[xo], bq = rq[xo + nw] - rq[xo];
+        const uint32_t old = V.pk[k][slot_r];
+        const uint32_t obs = old & 0x1fffu, obq = 255u * obs - (old >> 13);
+        V.ws[k] += bs - obs;
+        V.wq[k] += bq - obq;
+        V.pk[k][slot_w] = bs | ((255u * bs - bq) << 13);
+        if (emit) vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)V.ws[k], V.wq[k], area);
+      }
+    }
+    variance_rows<NH, PH, R0 + 1>(V, rs, rq, lds_pitch, nr, y0, ys, gnx, gny, nw, area, vout);
+  }
+}
+
+template <int CMAX, int NH>   // CMAX columns per thread: level width <= PI_THREADS * CMAX; NH: 0, or norm_h with the variance ring
+__global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integral(
     const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_step, int rows, int cols,
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
     uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
@@ -228,6 +274,16 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
   uint32_t col_s[CMAX], col_q[CMAX];
 #pragma unroll
   for (int k = 0; k < CMAX; k++) col_s[k] = col_q[k] = 0;
+  VarRing V;
+  if (NH > 0) {
+#pragma unroll
+    for (int k = 0; k < VR_COLS; k++) {
+      V.ws[k] = V.wq[k] = 0;
+#pragma unroll
+      for (int i = 0; i < VR_RING; i++) V.pk[k][i] = 0;
+    }
+  }
+  int ph = 0;
   for (int x = threadIdx.x; x < lds_pitch; x += PI_THREADS) xt_s[x] = x < w ? xtab[L.xtab_ofs + x] : 0u;
   __syncthreads();
 
@@ -341,13 +397,24 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
         }
       }
     }
+    if (NH > 0) {
+      // A.6a fused in, from the row prefixes of this chunk (see variance_rows); R == 8 on this route
+      if (vnf && L.nx > 0) {
+        float* vout = vnf + (size_t)frame * grid_stride + L.grid_ofs;
+        const double area = (double)(norm_w * norm_h);
+        if (ph == 0) variance_rows<NH ? NH : 1, 0, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        else if (ph == 1) variance_rows<NH ? NH : 1, 1, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        else variance_rows<NH ? NH : 1, 2, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+      }
+      ph = ph == 2 ? 0 : ph + 1;
+    }
     __syncthreads();
     // Phase 3 (A.6a fused in): the variance factor of every window whose inner rect ENDS in this chunk.  Its 8 integral
     // words are this workgroup's own stores -- the bottom row from this chunk, the top row norm_h rows up -- drained by
     // the barrier above (s_waitcnt vmcnt(0) precedes it) and never read by this CU before their final value was
     // written, so they come back from L2 (or L1) current; no other kernel has to re-read the integrals for this.
     // Uses no LDS: the wavefronts that finish first go on to the next chunk's phase 1.
-    if (vnf && Q && L.nx > 0) {
+    if (vnf && Q && L.nx > (NH > 0 ? VR_COLS * PI_THREADS : 0)) {   // NH > 0: only the grid columns beyond the ring's
       const int ys = L.ystep, gnx = L.nx, gny = L.ny;
       // window row y = gy*ys has its bottom integral row at y + 1 + norm_h; rows y0+1 .. y0+nr were finished just now
       int gy_lo = max(y0 - norm_h, 0);
@@ -371,7 +438,7 @@ __global__ __launch_bounds__(PI_THREADS) void k_pyramid_integral(
           qt[u] = Q + top; qb[u] = qt[u] + (size_t)norm_h * pitch;
           vo[u] = vout + (size_t)gy * gnx;
         }
-        for (uint32_t gx = threadIdx.x; (int)gx < gnx; gx += PI_THREADS) {
+        for (uint32_t gx = threadIdx.x + (NH > 0 ? VR_COLS * PI_THREADS : 0); (int)gx < gnx; gx += PI_THREADS) {
           const uint32_t lo = gx * (uint32_t)ys * 4u, hi = lo + (uint32_t)norm_w * 4u;   // byte offsets
           uint32_t s00[PV], s01[PV], s10[PV], s11[PV], q00[PV], q01[PV], q10[PV], q11[PV];
 #pragma unroll
@@ -499,13 +566,23 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   }
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
   const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
-#define HC_PI(C)                                                                                                  \
-  hipLaunchKernelGGL((k_pyramid_integral<C>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
+#define HC_PI(C, NH)                                                                                              \
+  hipLaunchKernelGGL((k_pyramid_integral<C, NH>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                      levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
                      norm_w, norm_h)
-  if (max_w <= 2 * PI_THREADS) HC_PI(2);
-  else if (max_w <= 4 * PI_THREADS) HC_PI(4);
-  else if (max_w <= 8 * PI_THREADS) HC_PI(8);
+  // variance factors from the row prefixes in LDS (register ring, variance_rows): chunks of 8 rows, at most two grid
+  // columns per thread, the stock inner-rect heights, box sums that fit the packed ring word.  Anything else reads the
+  // integrals back (NH = 0).  HC_VAR_RING=0 pins the old route (A/B).
+  static const bool ring_ok = [] { const char* e = getenv("HC_VAR_RING"); return !e || atoi(e) != 0; }();
+  const bool ring = ring_ok && vnf && sq && R == 8 && PI_THREADS == 512 && norm_w <= 32 &&
+                    (norm_h == 18 || norm_h == 22);
+  if (max_w <= 2 * PI_THREADS) {
+    if (ring && norm_h == 18) HC_PI(2, 18);
+    else if (ring) HC_PI(2, 22);
+    else HC_PI(2, 0);
+  }
+  else if (max_w <= 4 * PI_THREADS) HC_PI(4, 0);
+  else if (max_w <= 8 * PI_THREADS) HC_PI(8, 0);
   else return (int)hipErrorInvalidValue;
 #undef HC_PI
   HC_LAUNCH_CHECK();
