@@ -340,3 +340,27 @@ def test_shared_prep_pass_equals_separate_contexts(pkg, oracle, synth, names, sh
     ctxs[0].configure(rows, cols, 1.1, 2, (30, 30), (0, 0), max_batch=nf)
     with pytest.raises(pkg.HipCascadeError):
         ctxs[1].enqueue_host(batches[0])
+
+
+def test_cpp_drivers_make_their_own_frames(pkg, oracle, synth, tmp_path):
+    """throughput_demo and multi_gpu_demo with `synth:planted:<first>` instead of a frame file: the C++ generator
+    (hip_cascade/synth.hpp) feeds the batched C ABI, and what comes back equals the oracle on the frames the Python
+    generator makes for the same indices."""
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    n, first = 7, 40
+    frames = synth.make_frames("planted", n, 240, 320, first=first)
+    oc = oracle.OracleCascade(oracle.cascade_path("alt"))
+    want = [oc.detect(fr, 1.1, 2, (30, 30))[0] for fr in frames]
+    total = sum(len(w) for w in want)
+    assert total > 0
+    out = tmp_path / "boxes.hcbx"
+    r = subprocess.run([os.path.join(libdir, "multi_gpu_demo"), oracle.cascade_path("alt"), "synth:planted:%d" % first, str(n), "240", "320",
+                        "1", "4", "2", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = pkg.load_boxes(str(out))
+    for i in range(n):
+        assert np.array_equal(got[i], want[i]), i
+    r = subprocess.run([os.path.join(libdir, "throughput_demo"), oracle.cascade_path("alt"), "synth:planted:%d" % first, str(n), "240", "320",
+                        "4", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert ("%d boxes per pass" % total) in r.stdout, r.stdout

@@ -287,3 +287,20 @@ def test_compiled_stages_belong_to_exactly_their_cascade(pkg, oracle, tmp_path):
         subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag, str(nst), str(out)],
                               stdout=subprocess.DEVNULL)
         assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag
+
+
+def test_cpp_synthetic_frames_equal_the_python_generator(pkg, synth, tmp_path):
+    """SURVEY 8d asks for ONE deterministic generator in C++ and Python: hip_cascade/synth.hpp (what throughput_demo and
+    multi_gpu_demo feed themselves with) writes the same bytes as synth.py for every family, ragged sizes included."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "synth_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(root, "ugproj-detector_amd", "hip_cascade"),
+                           "-o", exe, os.path.join(root, "tests", "tools", "synth_check.cpp")])
+    face = os.path.join(root, "ugproj-detector_amd", "data", "face64.u8")
+    for kind, rows, cols, first, count in [("noise", 37, 53, 0, 2), ("texture", 61, 83, 5, 2), ("planted", 240, 320, 0, 3),
+                                           ("planted", 360, 640, 100, 1), ("planted", 130, 131, 7, 1)]:
+        out = str(tmp_path / "f.u8")
+        subprocess.check_call([exe, face, kind, str(rows), str(cols), str(first), str(count), out])
+        got = np.fromfile(out, np.uint8).reshape(count, rows, cols)
+        want = synth.make_frames(kind, count, rows, cols, first=first)
+        assert np.array_equal(got, want), (kind, rows, cols, int((got != want).sum()))

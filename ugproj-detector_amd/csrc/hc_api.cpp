@@ -383,7 +383,10 @@ bool stage_sum_is_exact(const hc::Model& m, const hc::ModelStage& s) {
   }
   // The device also forms bsum = sum(right) and adds [v < thr] * (left - right) per stump: every partial sum of that is
   // bounded by sum |right| + sum (|left| + |right|) <= 2 * sum |leaf|, so twice the plain bound keeps all of it exact.
-  return 2 * units < 0x1p53L;
+  // The sliced finish (cascade_body.inc wave_scan_f64) runs one prefix scan over the partial sums of up to 64 windows of
+  // a stage: 64 * sum (|left| + |right|), plus bsum, stays below 128 * sum |leaf|.  (The four reference cascades have
+  // 7.6 to 15 bits to spare on the plain bound.)
+  return 128 * units < 0x1p53L;
 }
 
 // True when upstream's f32 feature value w0*(float)S0 + w1*(float)S1 [+ w2*(float)S2] is an exact integer computation for
@@ -857,7 +860,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
     hc_context_destroy(ctx);
     return set_err(HC_ERR_HIP, "cannot create the result stream / event");
   }
-  if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = atoi(e_);   // tuning knobs
+  if (const char* e_ = getenv("HC_SPARSE_MAX")) ctx->sparse_max = std::min(256, std::max(0, atoi(e_)));   // tuning knobs (a wavefront owns at most 64 of them)
   if (const char* e_ = getenv("HC_HOST_THREADS")) ctx->host_threads = std::max(1, atoi(e_));
   if (const char* e_ = getenv("HC_DEBUG_MAX_STAGES")) ctx->debug_max_stages = std::max(0, atoi(e_));
   if (const char* e_ = getenv("HC_ROW_STAGES")) ctx->row_stages = std::max(1, atoi(e_));

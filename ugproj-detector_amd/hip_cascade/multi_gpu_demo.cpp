@@ -1,7 +1,7 @@
 // multi_gpu_demo.cpp -- the frame-sharded path from plain C++: ONE process,
 // N contexts on N devices, one feeder thread per GPU, RCCL (ncclCommInitAll) only for the gather of box records.
 //
-//   multi_gpu_demo <cascade> <frames.u8> <nframes> <rows> <cols> [ngpus=all] [batch=32] [rounds=3] [out.hcbx] [minNeighbors=2]
+//   multi_gpu_demo <cascade> <frames.u8 | synth:kind[:first]> <nframes> <rows> <cols> [ngpus=all] [batch=32] [rounds=3] [out.hcbx] [minNeighbors=2]
 //
 // frames.u8: nframes tight 8-bit gray frames (the "video").  Every round runs the whole video: the global batch
 // g covers frames [g*N*B, (g+1)*N*B); inside it device d owns the contiguous block of B frames starting at
@@ -25,8 +25,50 @@
 #include <thread>
 #include <vector>
 
+#include <algorithm>
+#include <cstring>
+#include <unistd.h>
+
 #include "../../include/hip_cascade.h"
 #include "box_records.hpp"
+#include "synth.hpp"
+
+// frames.u8 argument: a file of tight 8-bit gray frames, or "synth:<noise|texture|planted>[:first]" -- frames first ..
+// first + nframes - 1 of the deterministic generator (hip_cascade/synth.hpp == ugproj-detector_amd/synth.py), made here
+// on a few threads; the face patch is data/face64.u8 next to this executable.
+static bool load_or_make_frames(const char* arg, unsigned char* frames, int nframes, int rows, int cols) {
+  const size_t fbytes = (size_t)rows * cols;
+  if (strncmp(arg, "synth:", 6) != 0) {
+    FILE* f = fopen(arg, "rb");
+    const bool ok = f && fread(frames, 1, (size_t)nframes * fbytes, f) == (size_t)nframes * fbytes;
+    if (f) fclose(f);
+    return ok;
+  }
+  std::string kind(arg + 6);
+  long first = 0;
+  const size_t colon = kind.find(':');
+  if (colon != std::string::npos) { first = atol(kind.c_str() + colon + 1); kind.resize(colon); }
+  char exe[4096];
+  const ssize_t len = readlink("/proc/self/exe", exe, sizeof exe - 1);
+  if (len <= 0) return false;
+  exe[len] = 0;
+  std::string dir(exe);
+  dir.resize(dir.rfind('/'));
+  try {
+    const std::vector<uint8_t> face = hip_cascade::synth::load_face_patch(dir + "/data/face64.u8");
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([&, t] {
+        for (int i = t; i < nframes; i += nt) hip_cascade::synth::make_frame(kind, rows, cols, (uint64_t)(first + i), face, frames + (size_t)i * fbytes);
+      });
+    for (auto& x : th) x.join();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return false;
+  }
+  return true;
+}
 
 using hip_cascade::RECORD_INTS;
 
@@ -71,9 +113,7 @@ int main(int argc, char** argv) {
   void* pool = nullptr;
   HC(hc_host_alloc((size_t)nframes * fbytes, &pool));            // page-locked frame pool: async H2D
   unsigned char* frames = (unsigned char*)pool;
-  FILE* f = fopen(argv[2], "rb");
-  if (!f || fread(frames, 1, (size_t)nframes * fbytes, f) != (size_t)nframes * fbytes) { fprintf(stderr, "cannot read frames\n"); return 1; }
-  fclose(f);
+  if (!load_or_make_frames(argv[2], frames, nframes, rows, cols)) { fprintf(stderr, "cannot read / make frames\n"); return 1; }
   hc_cascade* casc = nullptr;
   HC(hc_cascade_load(argv[1], &casc));
 

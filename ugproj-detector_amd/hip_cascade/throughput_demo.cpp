@@ -1,7 +1,7 @@
 // throughput_demo.cpp -- the batched C ABI driven from plain C++ (no Python, no torch, no HIP headers):
 // two contexts software-pipelined, frames handed over as HOST buffers (so the rate printed here is the
 // PCIe-inclusive one: H2D of every frame + kernels + D2H of candidates + host grouping).
-//   throughput_demo <cascade> <frames.u8> <nframes> <rows> <cols> [batch=32] [rounds=8] [pool=pageable|pinned|registered]
+//   throughput_demo <cascade> <frames.u8 | synth:kind[:first]> <nframes> <rows> <cols> [batch=32] [rounds=8] [pool=pageable|pinned|registered]
 // pool: where the frames live on the host -- plain pageable memory (what cv::VideoCapture hands the reference),
 // a page-locked pool from hc_host_alloc, or the pageable buffer pinned in place with hc_host_register.
 // frames.u8: nframes tight 8-bit gray frames.  Prints one line per round and a summary:
@@ -13,7 +13,49 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <thread>
+#include <unistd.h>
+
 #include "../../include/hip_cascade.h"
+#include "synth.hpp"
+
+// frames.u8 argument: a file of tight 8-bit gray frames, or "synth:<noise|texture|planted>[:first]" -- frames first ..
+// first + nframes - 1 of the deterministic generator (hip_cascade/synth.hpp == ugproj-detector_amd/synth.py), made here
+// on a few threads; the face patch is data/face64.u8 next to this executable.
+static bool load_or_make_frames(const char* arg, unsigned char* frames, int nframes, int rows, int cols) {
+  const size_t fbytes = (size_t)rows * cols;
+  if (strncmp(arg, "synth:", 6) != 0) {
+    FILE* f = fopen(arg, "rb");
+    const bool ok = f && fread(frames, 1, (size_t)nframes * fbytes, f) == (size_t)nframes * fbytes;
+    if (f) fclose(f);
+    return ok;
+  }
+  std::string kind(arg + 6);
+  long first = 0;
+  const size_t colon = kind.find(':');
+  if (colon != std::string::npos) { first = atol(kind.c_str() + colon + 1); kind.resize(colon); }
+  char exe[4096];
+  const ssize_t len = readlink("/proc/self/exe", exe, sizeof exe - 1);
+  if (len <= 0) return false;
+  exe[len] = 0;
+  std::string dir(exe);
+  dir.resize(dir.rfind('/'));
+  try {
+    const std::vector<uint8_t> face = hip_cascade::synth::load_face_patch(dir + "/data/face64.u8");
+    const int nt = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+      th.emplace_back([&, t] {
+        for (int i = t; i < nframes; i += nt) hip_cascade::synth::make_frame(kind, rows, cols, (uint64_t)(first + i), face, frames + (size_t)i * fbytes);
+      });
+    for (auto& x : th) x.join();
+  } catch (const std::exception& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return false;
+  }
+  return true;
+}
 
 #define CHECK(x) do { int rc_ = (x); if (rc_ != HC_OK) { fprintf(stderr, "%s -> %d: %s\n", #x, rc_, hc_last_error()); return 2; } } while (0)
 
@@ -35,9 +77,7 @@ int main(int argc, char** argv) {
     if (pool == "registered") CHECK(hc_host_register(frames, total_bytes));
     else if (pool != "pageable") { fprintf(stderr, "unknown pool %s\n", pool.c_str()); return 64; }
   }
-  FILE* f = fopen(argv[2], "rb");
-  if (!f || fread(frames, 1, total_bytes, f) != total_bytes) { fprintf(stderr, "cannot read frames\n"); return 1; }
-  fclose(f);
+  if (!load_or_make_frames(argv[2], frames, nframes, rows, cols)) { fprintf(stderr, "cannot read / make frames\n"); return 1; }
   hc_cascade* casc = nullptr;
   if (hc_cascade_load(argv[1], &casc) != HC_OK) { fprintf(stderr, "cannot load cascade: %s\n", hc_last_error()); return 1; }
   hc_context* ctx[2] = {nullptr, nullptr};
