@@ -72,6 +72,14 @@ HC_API int  hc_cascade_dump(const hc_cascade* c, float* stage_thr, int32_t* stag
  * stage.  Results are identical either way (tests/test_gpu_parity.py, HC_SPEC=0 switches the compiled stages off).
  * No counterpart in the reference: cv::CascadeClassifier has one evaluation path.  Pure host code. */
 HC_API int  hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages);
+/* Compiled early stages for a cascade the library was not built with (a retrained haarcascade_frontalface_alt2, say --
+ * the file the shipped configuration selects, reference conf/apink.mrchu.720p.cfg:10):
+ *   tools/build_spec_plugin.sh <cascade.xml|.hcc> <out.so> [stages]
+ * generates the stage code (tools/gen_spec.py) and compiles it, with the very same kernel text, into a small shared
+ * object; this call (or HC_SPEC_PLUGINS=a.so:b.so in the environment) registers it for the rest of the process.
+ * Contexts created afterwards for a cascade with that exact hash run the compiled stages; every other cascade is
+ * unaffected.  HC_ERR_UNSUPPORTED when the object was built from another version of the kernel sources. */
+HC_API int  hc_spec_plugin_load(const char* path);
 
 /* ---- the call: replaces cv::CascadeClassifier::detectMultiScale
  *      (reference src/tracker/detector.cc:25-31) ------------------------------------------

@@ -74,6 +74,7 @@ _SIGS = {
     "hc_cascade_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
     "hc_cascade_counts": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 3),
     "hc_cascade_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "hc_spec_plugin_load": (C.c_int, [C.c_char_p]),
     "hc_context_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hc_cascade_dump": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
@@ -390,6 +391,11 @@ class Context:
         if a.size:
             _check(lib.hc_context_read_tap(self._h, frame, level_index, what, a.ctypes.data, a.nbytes))
         return a
+
+
+def load_spec_plugin(path):
+    """register compiled early stages built for another cascade (tools/build_spec_plugin.sh)"""
+    _check(lib.hc_spec_plugin_load(os.fsencode(path)))
 
 
 def alloc_count():

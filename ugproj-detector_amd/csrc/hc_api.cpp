@@ -6,6 +6,7 @@
 // entry point needs a HIP device and reports HC_ERR_NO_DEVICE / HC_ERR_HIP otherwise.
 
 #include <hip/hip_runtime_api.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -470,7 +471,44 @@ unsigned long long model_hash(const hc::Model& m) {
   return h;
 }
 
+// compiled-stage units from HC_SPEC_PLUGINS (colon-separated shared objects), loaded once before the first lookup
+int plugin_load(const char* path);
+void ensure_env_plugins() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* e = getenv("HC_SPEC_PLUGINS");
+    if (!e) return;
+    std::string s(e);
+    size_t a = 0;
+    while (a <= s.size()) {
+      const size_t b = s.find(':', a);
+      const std::string one = s.substr(a, b == std::string::npos ? std::string::npos : b - a);
+      if (!one.empty() && plugin_load(one.c_str()) != HC_OK) fprintf(stderr, "hip_cascade: HC_SPEC_PLUGINS: %s\n", g_err.c_str());
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+  });
+}
+
+int plugin_load(const char* path) {
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return set_err(HC_ERR_IO, std::string("cannot load the compiled-stage plug-in: ") + dlerror());
+  typedef int (*abi_fn)(void);
+  typedef const void* (*unit_fn)(void);
+  const abi_fn abi = (abi_fn)dlsym(h, "hc_spec_plugin_abi");
+  const unit_fn unit = (unit_fn)dlsym(h, "hc_spec_plugin_unit");
+  if (!abi || !unit) { dlclose(h); return set_err(HC_ERR_FORMAT, std::string(path) + " is not a hip_cascade compiled-stage plug-in"); }
+  if (abi() != hc::SPEC_PLUGIN_ABI) {
+    dlclose(h);
+    return set_err(HC_ERR_UNSUPPORTED, std::string(path) + " was built against another version of the kernel sources: rebuild it "
+                                                             "(tools/build_spec_plugin.sh)");
+  }
+  if (hc::spec_register((const hc::SpecUnit*)unit()) != 0) { dlclose(h); return set_err(HC_ERR_FORMAT, std::string(path) + ": empty unit"); }
+  return HC_OK;                       // the object stays loaded for the life of the process: its kernels are launched from it
+}
+
 int upload_model(hc_context* c) {
+  ensure_env_plugins();
   const hc::Model& m = c->casc->model;
   std::vector<hc::DevNode> nd[2];
   for (int k = 0; k < 2; k++) {
@@ -801,6 +839,7 @@ int hc_cascade_compiled_stages(const hc_cascade* c, uint64_t* hash, int* nstages
   const hc::Model& m = c->model;
   const unsigned long long h = model_hash(m);
   int n = 0;
+  ensure_env_plugins();
   if (weights_are_small_integers(m)) (void)hc::spec_lookup(h, m.win_w, m.win_h, &n);
   if (hash) *hash = (uint64_t)h;
   if (nstages) *nstages = n;
@@ -1625,6 +1664,11 @@ int hc_detect_multiscale_reread(hc_cascade* c, hc_rect* out, int out_capacity, i
 }
 
 long long hc_debug_alloc_count(void) { return g_alloc_count.load(); }
+
+int hc_spec_plugin_load(const char* path) {
+  if (!path) return set_err(HC_ERR_ARG, "null path");
+  return plugin_load(path);
+}
 
 int hc_context_set_rerun_on_overflow(hc_context* ctx, int allow) {
   if (!ctx) return set_err(HC_ERR_ARG, "null context");

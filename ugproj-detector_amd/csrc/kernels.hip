@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "device_types.h"
 #include "kernels.h"
@@ -522,11 +524,34 @@ static const SpecUnitFn spec_units[] = {
 static const SpecUnitFn spec_units[] = {nullptr};   // instrumented / word-offset builds run the generic kernel only
 #endif
 
+// Units that arrive at run time (hc_spec_plugin_load: a cascade the library was not built with, compiled into its own
+// small shared object by tools/build_spec_plugin.sh).  Ids continue behind the built-in units; units are never removed.
+static std::mutex g_spec_mu;
+static std::vector<const SpecUnit*> g_spec_extra;
+
+static const SpecUnit* spec_unit_by_id(int id) {   // 1-based
+  constexpr int nb = (int)(sizeof(spec_units) / sizeof(spec_units[0]));
+  if (id >= 1 && id <= nb) return spec_units[id - 1] ? spec_units[id - 1]() : nullptr;
+  std::lock_guard<std::mutex> l(g_spec_mu);
+  const int k = id - nb - 1;
+  return k >= 0 && k < (int)g_spec_extra.size() ? g_spec_extra[k] : nullptr;
+}
+
+int spec_register(const SpecUnit* u) {
+  if (!u || !u->launch || u->nstages <= 0) return -1;
+  std::lock_guard<std::mutex> l(g_spec_mu);
+  for (const SpecUnit* e : g_spec_extra)
+    if (e->hash == u->hash && e->win_w == u->win_w && e->win_h == u->win_h) return 0;     // already there
+  g_spec_extra.push_back(u);
+  return 0;
+}
+
 int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages) {
-  int id = 0;
-  for (const SpecUnitFn fn : spec_units) {
-    id++;
-    const SpecUnit* u = fn ? fn() : nullptr;
+  constexpr int nb = (int)(sizeof(spec_units) / sizeof(spec_units[0]));
+  int nextra;
+  { std::lock_guard<std::mutex> l(g_spec_mu); nextra = (int)g_spec_extra.size(); }
+  for (int id = 1; id <= nb + nextra; id++) {
+    const SpecUnit* u = spec_unit_by_id(id);
     if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h) {
       if (nstages) *nstages = u->nstages;
       return id;
@@ -625,10 +650,11 @@ int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int ro
   // two builds of the same kernel text (cascade_body.inc): rect weights as f32, or -- when the host has shown that every
   // weight is a small integer with w0 == -1 and every weighted rect sum stays below 2^24 -- as exact integer arithmetic
   // compiled early stages for this cascade (args.spec from spec_lookup); -1: no instance for this launch shape
-  if (args.int_weights && args.spec > 0 && spec_units[args.spec - 1] && spec_units[args.spec - 1]()->tree == tree) {
-    const int rc = spec_units[args.spec - 1]()->launch(st, nframes, segments, rows, nwaves, lds_bytes, args);
+  const SpecUnit* unit = args.int_weights && args.spec > 0 ? spec_unit_by_id(args.spec) : nullptr;
+  if (unit && unit->tree == tree) {
+    const int rc = unit->launch(st, nframes, segments, rows, nwaves, lds_bytes, args);
     if (rc >= 0) {
-      if (compiled) *compiled = spec_units[args.spec - 1]()->nstages;
+      if (compiled) *compiled = unit->nstages;
       return rc;
     }
   }
