@@ -853,3 +853,47 @@ def test_capacity_error_keeps_the_rectangles(pkg, oracle, synth, tmp_path):
     assert r.returncode == 0, r.stderr
     got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
     assert np.array_equal(got, wantb)
+
+
+def test_retrained_cascade_runs_its_plugin_stages(pkg, oracle, synth):
+    """The shipped configuration selects haarcascade_frontalface_alt2 (reference conf/apink.mrchu.720p.cfg:10); a
+    retrained file of that shape has another hash and used to fall back to the generic tree path.  With its plug-in
+    registered (tools/build_spec_plugin.sh) a new context runs compiled stages for it; stage taps, raw candidates and
+    boxes equal the oracle's evaluation of the SAME modified file, before and after, batch and single frame."""
+    d = os.path.join(os.path.dirname(pkg.LIB_PATH), "build", "test_plugin")
+    so, hcc = os.path.join(d, "libhc_spec_alt2mod.so"), os.path.join(d, "alt2_mod.hcc")
+    assert os.path.exists(so) and os.path.exists(hcc), "make -C ugproj-detector_amd test-plugin (part of build())"
+    oc = oracle.OracleCascade(hcc)
+    frames = np.stack([synth.planted(360, 640, synth.frame_seed(50 + i), nfaces=4, min_size=40, max_size=120)[0] for i in range(20)])
+    want = [oc.detect(fr, 1.1, 2, (30, 30), (0, 0), want_taps=True) for fr in frames[:3]]
+    wantb = [oc.detect(fr, 1.1, 2, (30, 30))[0] for fr in frames]
+
+    def run(casc):
+        ctx = pkg.Context(casc)
+        ctx.configure(360, 640, 1.1, 2, (30, 30), (0, 0), max_batch=20, cand_capacity=1 << 13)
+        ctx.enable_stage_taps(True)
+        got = ctx.detect_host(frames)
+        raws = ctx.raw_candidates(20)
+        for f in range(3):
+            grouped, raw, otaps = want[f]
+            for li in range(len(ctx.levels())):
+                assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (f, li)
+            assert np.array_equal(raws[f], raw)
+        for f in range(20):
+            assert np.array_equal(got[f], wantb[f]), f
+        ctx.enable_stage_taps(False)
+        got = ctx.detect_host(frames)                       # the production (no-tap) instantiation
+        for f in range(20):
+            assert np.array_equal(got[f], wantb[f]), f
+        n = ctx.compiled_stages()
+        ctx.close()
+        return n
+    if os.environ.get("HC_SPEC") == "0":
+        pytest.skip("compiled stages switched off")
+    casc = pkg.Cascade(hcc)
+    already = casc.compiled_stages()[1] > 0                 # an earlier test of this process may have registered it
+    if not already:
+        assert run(casc) == 0                               # generic tree path
+        pkg.load_spec_plugin(so)
+    assert run(pkg.Cascade(hcc)) == 8                       # compiled stages from the plug-in
+    assert np.array_equal(pkg.Cascade(hcc).detect_multiscale(frames[0], 1.1, 2, 0, (30, 30)), wantb[0])

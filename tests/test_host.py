@@ -304,3 +304,31 @@ def test_cpp_synthetic_frames_equal_the_python_generator(pkg, synth, tmp_path):
         got = np.fromfile(out, np.uint8).reshape(count, rows, cols)
         want = synth.make_frames(kind, count, rows, cols, first=first)
         assert np.array_equal(got, want), (kind, rows, cols, int((got != want).sum()))
+
+
+def _test_plugin(pkg):
+    d = os.path.join(os.path.dirname(pkg.LIB_PATH), "build", "test_plugin")
+    so, hcc = os.path.join(d, "libhc_spec_alt2mod.so"), os.path.join(d, "alt2_mod.hcc")
+    if not (os.path.exists(so) and os.path.exists(hcc)):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(pkg.LIB_PATH), "test-plugin"])
+    return so, hcc
+
+
+def test_compiled_stage_plugin_registers_for_exactly_its_cascade(pkg, oracle):
+    """A cascade the library was not built with gets its compiled early stages from a plug-in
+    (tools/build_spec_plugin.sh -> hc_spec_plugin_load): afterwards exactly that cascade reports them.  Host-only (the
+    plug-in's kernels are cross-compiled for gfx950; tests/test_gpu_parity.py runs them)."""
+    so, hcc = _test_plugin(pkg)
+    stock = pkg.Cascade(oracle.cascade_path("alt2")).compiled_stages()
+    mod = pkg.Cascade(hcc)
+    h0, _ = mod.compiled_stages()
+    assert h0 != stock[0]
+    pkg.load_spec_plugin(so)
+    pkg.load_spec_plugin(so)                                  # registering twice is harmless
+    assert mod.compiled_stages() == (h0, 8)
+    assert pkg.Cascade(oracle.cascade_path("alt2")).compiled_stages() == stock
+    with pytest.raises(pkg.HipCascadeError) as e:
+        pkg.load_spec_plugin(pkg.LIB_PATH)                    # a shared object that is not a plug-in
+    assert e.value.code == -2
+    with pytest.raises(pkg.HipCascadeError):
+        pkg.load_spec_plugin("/nonexistent/plugin.so")

@@ -70,8 +70,12 @@ static_assert(sizeof(DevNode) == 48, "DevNode layout");
 // stage's leaf values is exact in any order (sparse stump-parallel mode is then bit-identical);
 // exact == 2: the same holds for every later stage as well
 // bsum: exact stump stages only -- the f64 sum of the right leaves, the value every stage sum starts from (0 otherwise)
-struct DevStage { int32_t first, count; float thr; int32_t exact; double bsum; };
-static_assert(sizeof(DevStage) == 24, "DevStage layout");
-struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };
+// pair: tree stage in PAIR FORM -- exact, every tree a root with one leaf branch and one second node (all of
+//   haarcascade_frontalface_alt2): a tree adds  other + go * ((lb - other) + [v1 < thr1] * (la - lb)),  go = the root
+//   sends the window to its second node.  psum = sum of the `other` leaves; the two f64 differences sit in the a / b
+//   words of the tree's two node records (dense node table only), DevTree::pad bit 0 says which root branch is the node.
+struct DevStage { int32_t first, count; float thr; int16_t exact, pair; double bsum; double psum; };
+static_assert(sizeof(DevStage) == 32, "DevStage layout");
+struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };   // pad bit 0 (pair form): the root's LEFT branch is the second node
 
 }  // namespace hc

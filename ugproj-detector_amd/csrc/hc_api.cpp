@@ -175,6 +175,7 @@ struct hc_context {
   bool allow_int_weights = true; // HC_INT_WEIGHTS=0: always the f32 feature arithmetic (A/B, debugging)
   bool bank_order = true;        // HC_BANK_ORDER=0: the sparse finish reads the stumps in the dense path's order
   bool allow_spec = true;        // HC_SPEC=0: never the compiled early stages (csrc/spec), always the generic kernel
+  bool pair_form = true;         // HC_PAIR_FORM=0: tree stages always walk their trees per lane (A/B, debugging)
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
   int row_stages = 2;            // stages 0 and 1 in row form (conflict-free LDS reads while 88 % of the windows are alive)
@@ -531,6 +532,9 @@ int upload_model(hc_context* c) {
     build_nodes(m, c->geom[k], ystep, nd[k]);
   }
   std::vector<hc::DevStage> st;
+  struct PairWords { int node; uint32_t a, b; };
+  std::vector<PairWords> pair_words;                 // dense node table only: the sparse finish keeps the child links
+  std::vector<std::pair<int, int>> pair_left;        // tree -> DevTree::pad
   std::vector<hc::DevTree> tr;
   std::vector<hc::DevStageKinds> kinds;
   for (const hc::ModelStage& s : m.stages) {
@@ -556,6 +560,37 @@ int upload_model(hc_context* c) {
         }
       }
       d.bsum = (double)bs;
+    }
+    if (!m.is_stump() && d.exact && c->pair_form) {
+      // pair form of a tree stage (device_types.h DevStage::pair): every tree a root with one leaf branch and one
+      // second node whose branches are both leaves
+      bool ok = true;
+      for (int i = 0; i < s.ntrees && ok; i++) {
+        const hc::ModelTree& t = m.trees[s.first_tree + i];
+        if (t.nnodes != 2) { ok = false; break; }
+        const hc::ModelNode &r = m.nodes[t.first_node], &q = m.nodes[t.first_node + 1];
+        ok = ((r.left == 1 && r.right <= 0) || (r.right == 1 && r.left <= 0)) && q.left <= 0 && q.right <= 0;
+      }
+      if (ok) {
+        long double ps = 0;
+        for (int i = 0; i < s.ntrees; i++) {
+          const hc::ModelTree& t = m.trees[s.first_tree + i];
+          const hc::ModelNode &r = m.nodes[t.first_node], &q = m.nodes[t.first_node + 1];
+          const bool leftnode = r.left == 1;
+          const double other = (double)m.leaves[t.first_leaf - (leftnode ? r.right : r.left)];
+          const double la = (double)m.leaves[t.first_leaf - q.left], lb = (double)m.leaves[t.first_leaf - q.right];
+          const double d1 = lb - other, d2 = la - lb;          // exact: differences of leaves of one stage (stage_sum_is_exact)
+          ps += other;
+          uint64_t b1, b2;
+          memcpy(&b1, &d1, 8);
+          memcpy(&b2, &d2, 8);
+          pair_words.push_back({t.first_node, (uint32_t)b1, (uint32_t)(b1 >> 32)});
+          pair_words.push_back({t.first_node + 1, (uint32_t)b2, (uint32_t)(b2 >> 32)});
+          pair_left.push_back({s.first_tree + i, leftnode ? 1 : 0});
+        }
+        d.pair = 1;
+        d.psum = (double)ps;
+      }
     }
     st.push_back(d);
     if (m.is_stump()) {
@@ -590,6 +625,7 @@ int upload_model(hc_context* c) {
     if (all) st[i].exact = 2;
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
+  for (const auto& pl : pair_left) tr[pl.first].pad = pl.second;
   c->int_weights = c->allow_int_weights && weights_are_small_integers(m);
   c->spec_id = c->int_weights && c->allow_spec ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
   if (c->int_weights)
@@ -600,11 +636,13 @@ int upload_model(hc_context* c) {
           memcpy(&d.w[k], &wi, 4);
         }
   int rc;
+  std::vector<hc::DevNode> ns[2] = {nd[0], nd[1]};   // the sparse finish reads its own copy of the node records (trees: with the child links)
+  for (int g = 0; g < 2; g++)
+    for (const PairWords& pw : pair_words) { nd[g][pw.node].a = pw.a; nd[g][pw.node].b = pw.b; }
   if ((rc = dev_upload(&c->d_nodes[0], nd[0]))) return rc;
   if ((rc = dev_upload(&c->d_nodes[1], nd[1]))) return rc;
   {
-    // the sparse finish reads its own copy of the node records: stump stages with an order-free sum in bank-spreading order
-    std::vector<hc::DevNode> ns[2] = {nd[0], nd[1]};
+    // ... stump stages with an order-free sum in bank-spreading order
     if (m.is_stump() && c->bank_order)
       for (int g = 0; g < 2; g++)
         for (const hc::DevStage& d : st)
@@ -911,6 +949,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_PAIR_FORM")) ctx->pair_form = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_BANK_ORDER")) ctx->bank_order = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));

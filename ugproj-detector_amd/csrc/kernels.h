@@ -50,7 +50,7 @@ int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages);
 // adds a unit that was not linked into the library (hc_spec_plugin_load); the object must outlive the process' use of it
 int spec_register(const SpecUnit* u);
 // layout check between the library and a plug-in built from another checkout of these sources
-constexpr int SPEC_PLUGIN_ABI = 3 * 1000 + (int)sizeof(CascadeArgs);
+constexpr int SPEC_PLUGIN_ABI = 4 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
 
 // YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
 struct SkinBounds { int32_t lo[3], hi[3]; };
