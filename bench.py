@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic frames per rank (0 = one per batch slot)")
     ap.add_argument("--kind", default="planted", choices=["planted", "texture", "noise"])
     ap.add_argument("--cascade", default="", help="override the config's cascade list (comma separated)")
+    ap.add_argument("--semantics", default="cv4", choices=["cv4", "cv24"],
+                    help="cv4: OpenCV >= 4 evaluation (BASELINE metric); cv24: the OpenCV 2.4.x evaluation of the same call "
+                         "(hc_context_set_semantics, SURVEY Appendix B) -- one cascade per run")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="frames of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs leg (configs 3 and 5 after the headline)")
@@ -247,9 +250,14 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
     # Two pipeline slots (workspaces): batch i+1 is enqueued before batch i is waited for, so the host-side
     # candidate decode / rectangle grouping / record packing of batch i overlaps the kernels of batch i+1.
     # Every step still does all of its work.  A slot holds one context per cascade of the config.
+    cv24 = args.semantics == "cv24"
+    if cv24 and len(cascs) != 1:
+        raise SystemExit("--semantics cv24 runs one cascade per context (no shared prep pass): use --cascade")
     slots = []
     for _ in range(2):
         cs = [pkg.Context(casc, device=E.devno, stream=E.stream) for casc in cascs]
+        if cv24:
+            cs[0].set_semantics(True)
         if len(cs) == 1:
             cs[0].configure(rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"],
                             max_batch=B, cand_capacity=4096)
@@ -321,7 +329,9 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
         def check(job):
             r, f = job
             fr = frames_np[f] if r == 0 else synth.make_frames(args.kind, 1, rows, cols, first=r * ndist + f)[0]
-            if len(jobs) >= E.nthreads or len(ocs) == 1:
+            if cv24:
+                per = [ocs[0].detect_cv24(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0]]
+            elif len(jobs) >= E.nthreads or len(ocs) == 1:
                 per = [oc.detect(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0] for oc in ocs]
             else:        # few large frames, several cascades (config 5): the cascades of a frame side by side
                 with ThreadPoolExecutor(max_workers=len(ocs)) as ex2:
@@ -382,7 +392,7 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
         else:
             par = "frame-shard x%d, %s all-gather of box records" % (world, "RCCL" if args.backend == "nccl" else "gloo")
         out = {
-            "metric": "%dp frames/sec, %s, boxes bit-exact vs CPU oracle" % (rows, cnames),
+            "metric": "%dp frames/sec, %s%s, boxes bit-exact vs CPU oracle" % (rows, cnames, ", OpenCV 2.4.x semantics" if cv24 else ""),
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": min(world, E.ndev) if E.shared else world,
             "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak",
@@ -409,7 +419,7 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             traffic, traffic_src = None, None
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if tf and args.kind == "planted" and cfgno == 2 and names == cfg["cascades"]:
+            if tf and args.kind == "planted" and cfgno == 2 and names == cfg["cascades"] and not cv24:
                 try:
                     tj = json.load(open(tf[-1]))
                     traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"] * B / tj.get("frames_per_launch", 64))
@@ -423,6 +433,8 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
                                "launch_ms": round(per_launch[dom], 4),
                                "all_kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()}}
         ns = cfg["cpu_sample"] if cpu_sample < 0 else cpu_sample
+        if cv24:
+            ns = 0      # the oracle's 2.4 restatement is single-frame; the cpu_baseline leg times the >= 4 path only
         if ns > 0:
             # reported at any N: rank 0's host cores, the same frames (the other ranks wait at the closing barrier)
             cores = min(os.cpu_count() or 1, 16)   # the GPU box grants a 16-core CPU share per GPU
@@ -450,7 +462,7 @@ def rank_main(args):
                      timing=not args.no_timing_events)
     # Driver-visible numbers for BASELINE configs #3 and #5: only in the plain single-GPU default run, after the headline
     # measurement, never inside its timed region; a few steps each with their own oracle check.
-    plain = (E.world == 1 and not args.force_dist and args.config == 2 and not args.cascade and not args.batch
+    plain = (E.world == 1 and not args.force_dist and args.config == 2 and not args.cascade and not args.batch and args.semantics == "cv4"
              and not args.distinct and args.kind == "planted" and not args.no_extra
              and not os.environ.get("HC_DEBUG_MAX_STAGES"))
     if plain:

@@ -121,7 +121,8 @@ HC_API int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int cha
  * row / column of window origins not scanned, area-normalised rect weights, stage bias 0.0001f, and the cascade file's
  * STAGE TREE (parent / next; data/haarcascade_frontalface_alt_tree.xml:1303-1304) instead of a linear chain.
  * `flags` must contain CASCADE_SCALE_IMAGE (2), as the reference's call does; minNeighbors 0 returns the raw candidates.
- * Synchronous, host in / host out, not tuned.  Parity unpinned, like the rest.
+ * Synchronous, host in / host out, through a cached internal context like hc_detect_multiscale (the batched form:
+ * hc_context_set_semantics).  Parity unpinned, like the rest.
  * _taps: also returns, per scanned position (levels of hc_plan_query_cv24 concatenated, [gy][gx]), the number of stages
  * passed along the window's path through the stage tree, | 64 when the window was accepted. */
 HC_API int hc_detect_multiscale_cv24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes,
@@ -150,6 +151,15 @@ HC_API int  hc_host_unregister(void* p);
 /* stream: a hipStream_t to enqueue on, or NULL for a stream owned by the context. */
 HC_API int  hc_context_create(const hc_cascade* c, int device, void* stream, hc_context** out);
 HC_API void hc_context_destroy(hc_context* ctx);
+/* Which generation of the call the context evaluates; call before hc_context_configure (it drops the workspace).
+ * 0 (default): OpenCV >= 4, everything in this section as described.
+ * 1: OpenCV 2.4.x (Appendix B; see hc_detect_multiscale_cv24 above) as a batched, device-resident path: its own scale
+ *    loop and cvResize pyramid, f64 variance factors, then the same LDS-tiled band kernel with 2.4's node arithmetic
+ *    for cascades whose stages form a chain (alt, alt2, default), the window-at-a-time kernel for a real stage tree
+ *    (alt_tree).  Host or device frames, stage taps (HC_TAP_STAGES: stages passed, | 64 when accepted), raw candidates
+ *    and grouping (minNeighbors 0 = raw candidates) as 2.4 defines them.  Not available: shared prep passes, the
+ *    detectFaces path, pyramid / integral taps of the >= 4 layout keep their meaning (HC_TAP_VNF is empty). */
+HC_API int  hc_context_set_semantics(hc_context* ctx, int semantics);
 /* Fix geometry + call parameters and allocate the persistent workspace (no hipMalloc
  * happens on the detect path afterwards).  cand_capacity = raw candidates per frame
  * the workspace can hold (0 -> default 4096). */

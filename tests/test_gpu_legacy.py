@@ -100,3 +100,61 @@ def test_cv24_colour_input_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
         got = np.array([[int(v) for v in ln.split()] for ln in r.stdout.splitlines()], np.int32).reshape(-1, 4)
         assert np.array_equal(got, want) and len(want) > 0, mode
     assert not np.array_equal(want24, want4)
+
+
+@pytest.mark.parametrize("name", ["alt", "alt2", "default", "alt_tree"])
+def test_cv24_batched_context(pkg, oracle, synth, name):
+    """The 2.4 evaluation as a batched, device-resident path (hc_context_set_semantics): 6 frames of mixed families in one
+    batch -- the LDS-tiled band kernel with 2.4's node arithmetic for the chain cascades, the window-at-a-time kernel for
+    alt_tree's stage tree.  Stage taps of two frames, raw candidates (minNeighbors 0) and grouped boxes of all."""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    kinds = ["planted", "texture", "noise"]
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, 240, 320, first=500 + i)[0] for i in range(6)])
+    want = [oc.detect_cv24(fr, 1.1, 2, (30, 30), want_taps=True) for fr in frames]
+    ctx = pkg.Context(casc)
+    ctx.set_semantics(True)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=6, cand_capacity=1 << 14)
+    assert [(L.w, L.h, L.ystep, L.nx, L.ny) for L in ctx.levels()] == \
+        [(l["w"], l["h"], l["ystep"], l["nx"], l["ny"]) for l in oc.plan_cv24(240, 320, 1.1, (30, 30))]
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    raws = ctx.raw_candidates(6)
+    nraw = 0
+    for f in range(6):
+        grouped, raw, otaps = want[f]
+        if f in (0, 4):
+            for li in range(len(ctx.levels())):
+                assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (name, f, li)
+        assert np.array_equal(raws[f], raw), (name, f)
+        assert np.array_equal(got[f], grouped), (name, f)
+        nraw += len(raw)
+    assert nraw > 0
+    # the production instantiation (no taps), device-resident frames, then back to the >= 4 semantics on the same context
+    ctx.enable_stage_taps(False)
+    import torch
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    ctx.enqueue_device(d.data_ptr(), 6)
+    got2 = ctx.wait(6)
+    for f in range(6):
+        assert np.array_equal(got2[f], want[f][0]), (name, f)
+    ctx.set_semantics(False)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=6)
+    got4 = ctx.detect_host(frames)
+    for f in range(6):
+        assert np.array_equal(got4[f], oc.detect(frames[f], 1.1, 2, (30, 30))[0]), (name, f)
+
+
+def test_cv24_bench_route_720p(pkg, oracle, synth):
+    """bench.py --semantics cv24 as a test: 720p, alt, a batch of 24 through the tiled kernel; rank 0 checks frames against the
+    oracle's 2.4 restatement before it times anything."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--semantics", "cv24", "--batch", "24", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["parity"]["bit_exact"] is True and out["parity"]["frames_checked"] == 16 and out["parity"]["boxes"] > 0
+    assert "2.4" in out["metric"] and out["value"] > 0 and out["roofline"]["kernel"] == "k_cascade"

@@ -86,6 +86,7 @@ _SIGS = {
     "hc_detect_multiscale_reread": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "hc_debug_alloc_count": (C.c_longlong, []),
     "hc_context_set_rerun_on_overflow": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_context_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_convert_bgr2gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]),
     "hc_boxes_save": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hc_boxes_load": (C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
@@ -305,6 +306,11 @@ class Context:
     def enqueue_device(self, dptr, nframes, frame_stride=None, row_step=None):
         _check(lib.hc_detect_batch_enqueue(self._h, C.c_void_p(dptr), frame_stride or self.rows * self.cols,
                                            row_step or self.cols, nframes))
+
+    def set_semantics(self, cv24):
+        """False: OpenCV >= 4 (default); True: OpenCV 2.4.x (hc_context_set_semantics); call before configure()"""
+        _check(lib.hc_context_set_semantics(self._h, 1 if cv24 else 0))
+        self.cv24 = bool(cv24)
 
     def set_rerun_on_overflow(self, allow=True):
         """caller-owned device frames stay valid and unmodified until wait(): a candidate-workspace overflow re-runs by itself"""

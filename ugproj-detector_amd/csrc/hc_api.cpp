@@ -27,7 +27,15 @@
 #include "group_rects.h"
 #include "hc_internal.h"
 #include "kernels.h"
+#include "legacy_cv24.h"
+#include "legacy_cv24_host.h"
 #include "scale_plan.h"
+
+namespace hc {
+int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+int launch_cv24_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items, const uint32_t* sum,
+                         const uint32_t* sq, size_t int_stride, int norm_w, int norm_h, double inv_area, double* vnf, size_t grid_stride);
+}
 
 namespace {
 
@@ -151,6 +159,19 @@ struct hc_context {
 
   hc::Plan plan;
   bool configured = false;
+  // Which generation of the call the context evaluates (hc_context_set_semantics): 0 = OpenCV >= 4,
+  // 1 = OpenCV 2.4.x (Appendix B): its own scale loop, cvResize pyramid, f64 variance factors and node arithmetic; the
+  // LDS-tiled band kernel when the cascade's stage tree is a chain, the window-at-a-time kernel otherwise (alt_tree).
+  int semantics = 0;
+  hc::Cv24Host cv;
+  bool cv_chain = true;
+  double* d_vnf64 = nullptr;
+  hc::Cv24DevLevel* d_cvlevels = nullptr;
+  int* d_cvtab_ofs = nullptr;
+  short *d_cvtab_a0 = nullptr, *d_cvtab_a1 = nullptr;
+  hc::Cv24Node* d_cvnodes = nullptr;
+  hc::Cv24Tree* d_cvtrees = nullptr;
+  hc::Cv24Stage* d_cvstages = nullptr;
   // several cascades over the same frames (hc_context_configure_shared): the leader owns the pyramid integrals of
   // the union ladder, followers read them.  prep_seq counts the leader's enqueues; a follower scans each once.
   hc_context* leader = nullptr;
@@ -281,6 +302,9 @@ struct hc_context {
     h_cand = nullptr; h_count = nullptr;
     if (d_src_bgr) (void)hipFree(d_src_bgr);
     d_src_bgr = nullptr; src_rows = src_cols = 0;
+    void* cptrs[] = {d_vnf64, d_cvlevels, d_cvtab_ofs, d_cvtab_a0, d_cvtab_a1};
+    for (void* q : cptrs) if (q) (void)hipFree(q);
+    d_vnf64 = nullptr; d_cvlevels = nullptr; d_cvtab_ofs = nullptr; d_cvtab_a0 = d_cvtab_a1 = nullptr;
     void* fptrs[] = {d_bgr, d_gray, d_mask, d_lut, d_hist, d_msum, d_boxsums, d_boxes, d_idlevel, d_idx, d_idy,
                      d_mask_items[0], d_mask_items[1]};
     for (void* q : fptrs) if (q) (void)hipFree(q);
@@ -508,9 +532,20 @@ int plugin_load(const char* path) {
   return HC_OK;                       // the object stays loaded for the life of the process: its kernels are launched from it
 }
 
+void free_model_tables(hc_context* c) {
+  void* ptrs[] = {c->d_nodes[0], c->d_nodes[1], c->d_nodes_sparse[0], c->d_nodes_sparse[1], c->d_stages, c->d_trees, c->d_leaves,
+                  c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  c->d_nodes[0] = c->d_nodes[1] = c->d_nodes_sparse[0] = c->d_nodes_sparse[1] = nullptr;
+  c->d_stages = nullptr; c->d_trees = nullptr; c->d_leaves = nullptr; c->d_kinds = nullptr;
+  c->d_cvnodes = nullptr; c->d_cvtrees = nullptr; c->d_cvstages = nullptr;
+}
+
 int upload_model(hc_context* c) {
   ensure_env_plugins();
+  free_model_tables(c);
   const hc::Model& m = c->casc->model;
+  const bool cv24 = c->semantics == 1;
   std::vector<hc::DevNode> nd[2];
   for (int k = 0; k < 2; k++) {
     const int ystep = k + 1;
@@ -523,13 +558,16 @@ int upload_model(hc_context* c) {
 #endif
     c->tile_words[k] = (int)words;
     // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | 2 queues x band_rows*64 u16 | 3 counters (+pad)
+    const size_t vnf_bytes = cv24 ? 8 : 4;      // 2.4 semantics: f64 variance factors
 #ifndef HC_PLAIN_QUEUES
     // k_cascade LDS layout: tile | vnf[band_rows*64] f32 | bank matrix + survivor list, band_rows*64 u16 each | 32 counter words + ticket
-    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 136;
+    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (vnf_bytes + 2 * 2) + 136;
 #else
-    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (4 + 2 * 2) + 16;
+    c->lds_bytes[k] = words * 4 + (size_t)c->band_rows[k] * hc::TILE_POS * (vnf_bytes + 2 * 2) + 16;
 #endif
     build_nodes(m, c->geom[k], ystep, nd[k]);
+    if (cv24)       // B.6: the hidden cascade's area-normalised weights (the node records are in model order here)
+      for (size_t i = 0; i < nd[k].size(); i++) hc::cv24_weights(m, m.nodes[i], nd[k][i].w);
   }
   std::vector<hc::DevStage> st;
   struct PairWords { int node; uint32_t a, b; };
@@ -541,7 +579,7 @@ int upload_model(hc_context* c) {
     hc::DevStage d{};
     d.first = m.is_stump() ? m.trees[s.first_tree].first_node : s.first_tree;
     d.count = s.ntrees;
-    d.thr = s.thr;
+    d.thr = cv24 ? hc::cv24_stage_thr(s) : s.thr;
     d.exact = stage_sum_is_exact(m, s) ? 1 : 0;
     d.bsum = 0.0;
     if (m.is_stump() && d.exact) {
@@ -626,8 +664,19 @@ int upload_model(hc_context* c) {
   }
   for (const hc::ModelTree& t : m.trees) tr.push_back(hc::DevTree{t.first_node, t.nnodes, t.first_leaf, 0});
   for (const auto& pl : pair_left) tr[pl.first].pad = pl.second;
-  c->int_weights = c->allow_int_weights && weights_are_small_integers(m);
+  c->int_weights = !cv24 && c->allow_int_weights && weights_are_small_integers(m);
   c->spec_id = c->int_weights && c->allow_spec ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
+  if (cv24) {
+    c->cv_chain = hc::cv24_is_chain(m);
+    if (!c->cv_chain) {           // a real stage tree: tables of the window-at-a-time kernel
+      std::vector<hc::Cv24Node> cn;
+      std::vector<hc::Cv24Tree> ct;
+      std::vector<hc::Cv24Stage> cs;
+      int rc0 = hc::cv24_tree_tables(m, cn, ct, cs);
+      if (rc0 != HC_OK) return rc0;
+      if ((rc0 = dev_upload(&c->d_cvnodes, cn)) || (rc0 = dev_upload(&c->d_cvtrees, ct)) || (rc0 = dev_upload(&c->d_cvstages, cs))) return rc0;
+    }
+  }
   if (c->int_weights)
     for (int g = 0; g < 2; g++)
       for (hc::DevNode& d : nd[g])
@@ -729,7 +778,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   {
     const bool fused0 = use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty());
     int rc0;
-    if (!c->leader && !P.levels.empty() && (c->taps_enabled || !fused0) && (rc0 = ensure_pyr(c))) return rc0;
+    if (!c->leader && !P.levels.empty() && (c->taps_enabled || !fused0 || c->semantics == 1) && (rc0 = ensure_pyr(c))) return rc0;
     if (!P.levels.empty() && c->taps_enabled && (rc0 = ensure_taps(c))) return rc0;
   }
   HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), s));
@@ -743,7 +792,20 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
     // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
     const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
-    if (c->leader) {
+    if (c->semantics == 1) {
+      // OpenCV 2.4: cvResize pyramid (materialised), the two-pass integrals, f64 variance factors
+      if ((e = hc::launch_cv24_resize(s, nframes, (int)P.levels.size(), c->cv.max_pix, d_frames, frame_stride, row_step, P.rows, P.cols,
+                                      c->d_cvlevels, c->d_cvtab_ofs, c->d_cvtab_a0, c->d_cvtab_a1, c->d_pyr, pyr_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_cv24_resize launch: ") + hipGetErrorString((hipError_t)e));
+      if (timed) HIPCHK(hipEventRecord(c->ev[1], s));
+      if ((e = hc::launch_integral_rows(s, nframes, (int)P.row_items.size(), c->d_pyr, pyr_stride, c->d_levels, c->d_row_items, c->d_sum,
+                                        c->d_sq, int_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_integral_rows launch: ") + hipGetErrorString((hipError_t)e));
+      if (timed) HIPCHK(hipEventRecord(c->ev[2], s));
+      if ((e = hc::launch_integral_cols(s, nframes, (int)P.col_items.size(), c->d_levels, c->d_col_items, c->d_sum, c->d_sq, int_stride)))
+        return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
+      fused_variance = true;           // the generic k_variance below is the >= 4 gate; 2.4 has its own factor
+    } else if (c->leader) {
       // shared prep: the leader's kernels have produced (or are producing) the integrals of this very batch
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
@@ -779,7 +841,21 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
         (e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
+    if (c->semantics == 1 &&
+        (e = hc::launch_cv24_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq, int_stride,
+                                      m.win_w - 2, m.win_h - 2, c->cv.inv_area, c->d_vnf64, grid_stride)))
+      return set_err(HC_ERR_HIP, std::string("k_cv24_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
+    if (c->semantics == 1 && !c->cv_chain) {
+      // a real stage tree (alt_tree): window-at-a-time evaluation that walks parent / next / child
+      hc::Cv24Args T{};
+      T.levels = c->d_cvlevels; T.sum = c->d_sum; T.sq = c->d_sq; T.int_stride = int_stride; T.grid_stride = grid_stride;
+      T.stages = c->d_cvstages; T.trees = c->d_cvtrees; T.nodes = c->d_cvnodes; T.leaves = c->d_leaves; T.inv_area = c->cv.inv_area;
+      T.win_w = m.win_w; T.win_h = m.win_h; T.cand = c->d_cand; T.cand_count = c->d_count; T.cand_cap = (unsigned int)c->cand_cap;
+      T.taps = c->taps_enabled ? c->d_taps : nullptr;
+      if ((e = hc::launch_cv24_cascade(s, nframes, (int)P.levels.size(), c->cv.max_pos, T)))
+        return set_err(HC_ERR_HIP, std::string("k_cv24_cascade launch: ") + hipGetErrorString((hipError_t)e));
+    }
     // With one or two frames neither cascade launch fills 256 CUs and a band walk is a serial chain of tiles:
     // the two launches (independent: different levels) then run side by side on two streams.
     const bool side = equiv <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
@@ -790,9 +866,10 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     int launches = 0;
     c->last_compiled = 0;
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
+      if (c->semantics == 1 && !c->cv_chain) break;           // done by the window-at-a-time kernel above
       hc::CascadeArgs A{};
-      A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.grid_stride = grid_stride;
-      const bool seg = equiv <= c->seg_max_batch && c->n_seg_items[k] > 0;
+      A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.vnf64 = c->d_vnf64; A.grid_stride = grid_stride;
+      const bool seg = c->semantics == 0 && equiv <= c->seg_max_batch && c->n_seg_items[k] > 0;
       A.levels = c->d_levels;
       A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
       A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
@@ -808,6 +885,10 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.int_weights = c->int_weights ? 1 : 0;
       A.spec = c->spec_id;
       int compiled = 0;
+      if (c->semantics == 1)
+        e = hc::launch_cascade_cv24(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k],
+                                    c->lds_bytes[k], A);
+      else
       e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
                              c->band_waves[k], c->lds_bytes[k], A, &compiled);
       if (A.nbands > 0) c->last_compiled = launches++ == 0 ? compiled : std::min(c->last_compiled, compiled);
@@ -977,8 +1058,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   ctx->free_workspace();
-  void* ptrs[] = {ctx->d_nodes[0], ctx->d_nodes[1], ctx->d_nodes_sparse[0], ctx->d_nodes_sparse[1], ctx->d_stages, ctx->d_trees, ctx->d_leaves, ctx->d_kinds};
-  for (void* p : ptrs) if (p) (void)hipFree(p);
+  free_model_tables(ctx);
   for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -998,8 +1078,13 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->free_workspace();
   hc::Plan& P = ctx->plan;
-  int rc = hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_rows[0],
-                          ctx->band_rows[1], P, prep_scales);
+  const bool cv24 = ctx->semantics == 1;
+  if (cv24 && (prep_scales || leader)) return set_err(HC_ERR_UNSUPPORTED, "shared prep passes exist for the OpenCV >= 4 semantics only");
+  if (cv24 && (ctx->band_rows[0] != 16 || ctx->band_rows[1] != 16)) return set_err(HC_ERR_UNSUPPORTED, "2.4 semantics: 16-row bands only");
+  int rc = cv24 ? hc::build_plan_cv24(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_rows[0],
+                                      ctx->band_rows[1], P, ctx->cv)
+                : hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_rows[0],
+                                 ctx->band_rows[1], P, prep_scales);
   if (rc != HC_OK) return set_err(rc, "cannot plan this configuration");
   for (const hc::DevLevel& L : P.levels)
     if (L.nx > 65535 || L.ny_all > 65535 || P.levels.size() > 255) return set_err(HC_ERR_UNSUPPORTED, "frame too large");
@@ -1023,11 +1108,18 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
     HIPCHK(hipMemset(ctx->d_sum, 0, std::max<size_t>(B * P.int_words, 1) * 4));
     HIPCHK(hipMemset(ctx->d_sq, 0, std::max<size_t>(B * P.int_words, 1) * 4));
   }
-  if ((rc = dev_alloc(&ctx->d_vnf, B * P.grid_elems))) return rc;
+  if (cv24) {
+    if ((rc = dev_alloc(&ctx->d_vnf64, B * P.grid_elems))) return rc;
+    HIPCHK(hipMemset(ctx->d_vnf64, 0, std::max<size_t>(B * P.grid_elems, 1) * 8));
+    if ((rc = dev_upload(&ctx->d_cvlevels, ctx->cv.cl)) || (rc = dev_upload(&ctx->d_cvtab_ofs, ctx->cv.tab_ofs)) ||
+        (rc = dev_upload(&ctx->d_cvtab_a0, ctx->cv.tab_a0)) || (rc = dev_upload(&ctx->d_cvtab_a1, ctx->cv.tab_a1)))
+      return rc;
+  }
+  if ((rc = dev_alloc(&ctx->d_vnf, cv24 ? 1 : B * P.grid_elems))) return rc;
   ctx->cand_cap = B * ctx->cand_per_frame;
   if ((rc = dev_alloc(&ctx->d_cand, ctx->cand_cap))) return rc;
   if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
-  HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
+  if (!cv24) HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
   if ((rc = dev_upload(&ctx->d_levels, P.levels))) return rc;
   if ((rc = dev_upload(&ctx->d_xtab, P.xtab))) return rc;
   if ((rc = dev_upload(&ctx->d_ytab, P.ytab))) return rc;
@@ -1215,13 +1307,24 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
       const unsigned long long k = ctx->h_cand[i];
       const hc::DevLevel& L = P.levels[(k >> 32) & 0xFF];
       const int gy = (int)((k >> 16) & 0xFFFF), gx = (int)(k & 0xFFFF);
-      // Rect(cvRound(x*scale), cvRound(y*scale), winSize): int -> f32 times f32 scale
-      const hc_rect r{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale),
-                      (int)std::nearbyintf((float)(gy * L.ystep) * L.scale), L.win_w, L.win_h};
+      hc_rect r;
+      if (ctx->semantics == 1) {
+        // 2.4 (B.9): cvRound(x * factor) with the f64 factor of the scale loop
+        const double factor = ctx->cv.lv[(k >> 32) & 0xFF].factor;
+        r = hc_rect{(int)std::nearbyint(gx * L.ystep * factor), (int)std::nearbyint(gy * L.ystep * factor), L.win_w, L.win_h};
+      } else {
+        // Rect(cvRound(x*scale), cvRound(y*scale), winSize): int -> f32 times f32 scale
+        r = hc_rect{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale), (int)std::nearbyintf((float)(gy * L.ystep) * L.scale),
+                    L.win_w, L.win_h};
+      }
       grp.push_back(r);
       ctx->last_raw[i] = r;
     }
-    hc::group_rectangles(grp, ctx->min_neighbors, 0.2);     // GROUP_EPS upstream
+    if (ctx->semantics == 1) {
+      if (ctx->min_neighbors != 0) hc::group_rectangles(grp, std::max(ctx->min_neighbors, 1), 0.2);   // 2.4: minNeighbors 0 = raw
+    } else {
+      hc::group_rectangles(grp, ctx->min_neighbors, 0.2);   // GROUP_EPS upstream
+    }
   };
   if (nframes >= 4 && count >= 512 && ctx->host_threads > 1) {
     if (!ctx->pool) ctx->pool.reset(new WorkerPool(ctx->host_threads - 1));
@@ -1441,7 +1544,7 @@ int hc_faces_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_t
 }  // extern "C"
 namespace {
 int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min_neighbors, int min_w, int min_h, int max_w,
-                 int max_h, hc_context** out);
+                 int max_h, hc_context** out, int semantics = 0);
 }
 extern "C" {
 
@@ -1548,6 +1651,14 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
       const size_t n = (size_t)L.nx * L.ny_all;
       if (dst_bytes < n) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
       if (n) HIPCHK(hipMemcpy(dst, ctx->d_taps + (size_t)frame * P.grid_elems + L.grid_ofs, n, hipMemcpyDeviceToHost));
+      if (ctx->semantics == 1 && ctx->cv_chain) {
+        // 2.4 semantics report "stages passed along the window's path, | 64 when accepted"; the tiled kernel records the
+        // index of the failed stage of a chain (= stages passed) and nstages for an accepted window
+        const int nst = (int)ctx->casc->model.stages.size();
+        int8_t* t = (int8_t*)dst;
+        for (size_t i = 0; i < n; i++)
+          if (t[i] == (int8_t)nst) t[i] = (int8_t)(std::min(nst, 63) | 64);
+      }
       return HC_OK;
     }
     case HC_TAP_FACE_BGR: {
@@ -1596,7 +1707,7 @@ int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]) {
 namespace {
 // the per-cascade context of the synchronous calls, (re)configured for this geometry and these call parameters
 int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min_neighbors, int min_w, int min_h, int max_w,
-                 int max_h, hc_context** out) {
+                 int max_h, hc_context** out, int semantics) {
   int dev = 0, ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_err(HC_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
@@ -1607,7 +1718,7 @@ int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min
   for (size_t i = 0; i < lru.size(); i++) {
     hc_context* x = lru[i];
     const hc::Plan& P = x->plan;
-    if (x->device == dev && x->configured && P.rows == rows && P.cols == cols && P.scale_factor == scale_factor &&
+    if (x->device == dev && x->semantics == semantics && x->configured && P.rows == rows && P.cols == cols && P.scale_factor == scale_factor &&
         P.min_w == min_w && P.min_h == min_h && P.max_w == emw && P.max_h == emh && x->min_neighbors == min_neighbors) {
       std::rotate(lru.begin(), lru.begin() + i, lru.begin() + i + 1);
       *out = x;
@@ -1627,6 +1738,7 @@ int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min
     if (ctx->device != dev) { hc_context_destroy(ctx); ctx = nullptr; }
   }
   if (!ctx && (rc = hc_context_create(c, dev, nullptr, &ctx))) return rc;
+  if (ctx->semantics != semantics && (rc = hc_context_set_semantics(ctx, semantics))) { hc_context_destroy(ctx); return rc; }
   if ((rc = hc_context_configure(ctx, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, 1, 1 << 16))) {
     hc_context_destroy(ctx);
     return rc;
@@ -1713,6 +1825,71 @@ int hc_context_set_rerun_on_overflow(hc_context* ctx, int allow) {
   if (!ctx) return set_err(HC_ERR_ARG, "null context");
   ctx->rerun_caller_frames = allow != 0;
   return HC_OK;
+}
+
+int hc_context_set_semantics(hc_context* ctx, int semantics) {
+  if (!ctx) return set_err(HC_ERR_ARG, "null context");
+  if (semantics != 0 && semantics != 1) return set_err(HC_ERR_ARG, "semantics: 0 (OpenCV >= 4) or 1 (OpenCV 2.4)");
+  if (ctx->pending) return set_err(HC_ERR_STATE, "a batch is in flight");
+  if (semantics == ctx->semantics) return HC_OK;
+  const hc::Model& m = ctx->casc->model;
+  if (semantics == 1) {
+    if (m.has_tilted) return set_err(HC_ERR_UNSUPPORTED, "tilted features");
+    for (const hc::ModelNode& n : m.nodes)
+      for (int k = 0; k < 3; k++)
+        for (int j = 0; j < 4; j++)
+          if (n.rect[k][j] < 0) return set_err(HC_ERR_UNSUPPORTED, "rect coordinate out of range");
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->free_workspace();               // geometry, buffers and node tables all depend on the generation
+  ctx->semantics = semantics;
+  return upload_model(ctx);
+}
+
+// ---- legacy mode: the synchronous call with OpenCV 2.4.x semantics through a cached context
+int hc_detect_multiscale_cv24_taps(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,
+                                   int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h, hc_rect* out,
+                                   int out_capacity, int* out_count, int8_t* taps, size_t taps_capacity) {
+  if (!c || !gray || !out_count) return set_err(HC_ERR_ARG, "null argument");
+  *out_count = 0;
+  if (!(scale_factor > 1.0)) return set_err(HC_ERR_ARG, "scaleFactor must be > 1");
+  if (rows <= 0 || cols <= 0 || step_bytes < (size_t)cols) return set_err(HC_ERR_ARG, "bad image geometry");
+  if (!(flags & 2))   // CV_HAAR_SCALE_IMAGE: without it 2.4 scales the FEATURES instead of the image (not restated)
+    return set_err(HC_ERR_UNSUPPORTED, "legacy mode is the CASCADE_SCALE_IMAGE branch (the flag the reference passes)");
+  if (cols > 65535 || rows > 65535) return set_err(HC_ERR_UNSUPPORTED, "frame too large");
+  std::lock_guard<std::mutex> lock(c->mu);
+  hc_context* ctx = nullptr;
+  int rc = sync_context(c, rows, cols, scale_factor, min_neighbors, min_w, min_h, max_w, max_h, &ctx, 1);
+  if (rc) return rc;
+  const hc::Plan& P = ctx->plan;
+  if (taps) {
+    size_t need = 0;
+    for (const hc::DevLevel& L : P.levels) need += (size_t)L.nx * L.ny;
+    if (need > taps_capacity) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
+  }
+  ctx->taps_enabled = taps != nullptr;
+  if ((rc = hc_detect_batch_enqueue_host(ctx, gray, 0, step_bytes, 1))) { ctx->taps_enabled = false; return rc; }
+  std::vector<std::vector<hc_rect>> grouped;
+  rc = wait_core(ctx, grouped);
+  if (rc == HC_OK && taps) {
+    size_t at = 0;
+    for (size_t li = 0; li < P.levels.size() && rc == HC_OK; li++) {
+      const size_t n = (size_t)P.levels[li].nx * P.levels[li].ny;
+      if (n) rc = hc_context_read_tap(ctx, 0, (int)li, HC_TAP_STAGES, taps + at, n);
+      at += n;
+    }
+  }
+  ctx->taps_enabled = false;
+  if (rc) return rc;
+  return hc::deliver_sync_result(c, grouped[0], out, out_capacity, out_count);
+}
+
+int hc_detect_multiscale_cv24(hc_cascade* c, const uint8_t* gray, int rows, int cols, size_t step_bytes, double scale_factor,
+                              int min_neighbors, int flags, int min_w, int min_h, int max_w, int max_h, hc_rect* out,
+                              int out_capacity, int* out_count) {
+  return hc_detect_multiscale_cv24_taps(c, gray, rows, cols, step_bytes, scale_factor, min_neighbors, flags, min_w, min_h, max_w,
+                                        max_h, out, out_capacity, out_count, nullptr, 0);
 }
 
 int hc_convert_bgr2gray(const uint8_t* image, int rows, int cols, int channels, size_t step_bytes, uint8_t* gray,

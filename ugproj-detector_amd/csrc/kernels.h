@@ -14,6 +14,7 @@ struct CascadeArgs {
   const uint32_t* sum;        // per-frame integral arrays, frame stride int_stride words
   size_t int_stride;
   const float* vnf;           // per-frame grid arrays, frame stride grid_stride elements
+  const double* vnf64;        // OpenCV-2.4 semantics (casc_cv24 build): the f64 variance factors, same layout
   size_t grid_stride;
   const DevLevel* levels;
   const WorkItem* bands;      // bands of ONE ystep class (all share geometry g)

@@ -28,22 +28,26 @@ struct Cv24Stage { int32_t first_tree, ntrees; float thr; int32_t parent, next, 
 
 struct Cv24Args {
   const Cv24DevLevel* levels;
-  const uint32_t* sum;
+  const uint32_t* sum;           // frame f at + f * int_stride
   const uint32_t* sq;
+  size_t int_stride, grid_stride;
   const Cv24Stage* stages;
   const Cv24Tree* trees;
   const Cv24Node* nodes;
   const float* leaves;
   double inv_area;
   int win_w, win_h;
-  unsigned long long* cand;      // level << 32 | gy << 16 | gx
+  unsigned long long* cand;      // frame << 40 | level << 32 | gy << 16 | gx
   unsigned int* cand_count;
   unsigned int cand_cap;
   int8_t* taps;                  // nullable
 };
 
-int launch_cv24_resize(hipStream_t st, int nlevels, int max_pixels, const uint8_t* src, size_t row_step, int rows, int cols,
-                       const Cv24DevLevel* levels, const int* tab_ofs, const short* tab_a0, const short* tab_a1, uint8_t* pyr);
-int launch_cv24_cascade(hipStream_t st, int nlevels, int max_positions, const Cv24Args& args);
+// frame f of the batch: src + f * frame_stride -> pyr + f * pyr_stride
+int launch_cv24_resize(hipStream_t st, int nframes, int nlevels, int max_pixels, const uint8_t* src, size_t frame_stride, size_t row_step,
+                       int rows, int cols, const Cv24DevLevel* levels, const int* tab_ofs, const short* tab_a0, const short* tab_a1,
+                       uint8_t* pyr, size_t pyr_stride);
+// window-at-a-time evaluation with the cascade file's stage tree (cascades whose stages do not form a linear chain)
+int launch_cv24_cascade(hipStream_t st, int nframes, int nlevels, int max_positions, const Cv24Args& args);
 
 }  // namespace hc

@@ -15,11 +15,13 @@
 
 namespace hc {
 
-__global__ __launch_bounds__(256) void k_cv24_resize(const uint8_t* __restrict__ src, size_t row_step, int rows, int cols,
-                                                     const Cv24DevLevel* __restrict__ levels, const int* __restrict__ tab_ofs,
-                                                     const short* __restrict__ tab_a0, const short* __restrict__ tab_a1,
-                                                     uint8_t* __restrict__ pyr) {
+__global__ __launch_bounds__(256) void k_cv24_resize(const uint8_t* __restrict__ src, size_t frame_stride, size_t row_step, int rows,
+                                                     int cols, const Cv24DevLevel* __restrict__ levels,
+                                                     const int* __restrict__ tab_ofs, const short* __restrict__ tab_a0,
+                                                     const short* __restrict__ tab_a1, uint8_t* __restrict__ pyr, size_t pyr_stride) {
   const Cv24DevLevel L = levels[blockIdx.y];
+  src += (size_t)blockIdx.z * frame_stride;                    // one frame of the batch per grid z
+  pyr += (size_t)blockIdx.z * pyr_stride;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= L.w * L.h) return;
   const int y = i / L.w, x = i - y * L.w;
@@ -50,8 +52,9 @@ __global__ __launch_bounds__(256) void k_cv24_cascade(Cv24Args A) {
   if (i >= L.nx * L.ny) return;
   const int gy = i / L.nx, gx = i - gy * L.nx;
   const int x = gx * L.ystep, y = gy * L.ystep;
-  const uint32_t* S = A.sum + L.int_ofs;
-  const uint32_t* Q = A.sq + L.int_ofs;
+  const int frame = blockIdx.z;
+  const uint32_t* S = A.sum + (size_t)frame * A.int_stride + L.int_ofs;
+  const uint32_t* Q = A.sq + (size_t)frame * A.int_stride + L.int_ofs;
   const int p = L.int_pitch;
   const int8_t eq[4] = {1, 1, (int8_t)(A.win_w - 2), (int8_t)(A.win_h - 2)};
   const double mean = (double)cv24_box(S, p, x, y, eq) * A.inv_area;
@@ -86,24 +89,26 @@ __global__ __launch_bounds__(256) void k_cv24_cascade(Cv24Args A) {
       si = A.stages[si].next;
     }
   }
-  if (A.taps) A.taps[L.grid_ofs + i] = (int8_t)(min(passed, 63) | (accept ? 64 : 0));
+  if (A.taps) A.taps[(size_t)frame * A.grid_stride + L.grid_ofs + i] = (int8_t)(min(passed, 63) | (accept ? 64 : 0));
   if (accept) {
     const unsigned int slot = atomicAdd(A.cand_count, 1u);
-    if (slot < A.cand_cap) A.cand[slot] = ((unsigned long long)blockIdx.y << 32) | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+    if (slot < A.cand_cap)
+      A.cand[slot] = ((unsigned long long)frame << 40) | ((unsigned long long)blockIdx.y << 32) | ((unsigned long long)gy << 16) | (unsigned long long)gx;
   }
 }
 
-int launch_cv24_resize(hipStream_t st, int nlevels, int max_pixels, const uint8_t* src, size_t row_step, int rows, int cols,
-                       const Cv24DevLevel* levels, const int* tab_ofs, const short* tab_a0, const short* tab_a1, uint8_t* pyr) {
-  if (nlevels == 0) return 0;
-  hipLaunchKernelGGL(k_cv24_resize, dim3((max_pixels + 255) / 256, nlevels), dim3(256), 0, st, src, row_step, rows, cols, levels,
-                     tab_ofs, tab_a0, tab_a1, pyr);
+int launch_cv24_resize(hipStream_t st, int nframes, int nlevels, int max_pixels, const uint8_t* src, size_t frame_stride, size_t row_step,
+                       int rows, int cols, const Cv24DevLevel* levels, const int* tab_ofs, const short* tab_a0, const short* tab_a1,
+                       uint8_t* pyr, size_t pyr_stride) {
+  if (nlevels == 0 || nframes == 0) return 0;
+  hipLaunchKernelGGL(k_cv24_resize, dim3((max_pixels + 255) / 256, nlevels, nframes), dim3(256), 0, st, src, frame_stride, row_step, rows,
+                     cols, levels, tab_ofs, tab_a0, tab_a1, pyr, pyr_stride);
   return (int)hipGetLastError();
 }
 
-int launch_cv24_cascade(hipStream_t st, int nlevels, int max_positions, const Cv24Args& args) {
-  if (nlevels == 0 || max_positions == 0) return 0;
-  hipLaunchKernelGGL(k_cv24_cascade, dim3((max_positions + 255) / 256, nlevels), dim3(256), 0, st, args);
+int launch_cv24_cascade(hipStream_t st, int nframes, int nlevels, int max_positions, const Cv24Args& args) {
+  if (nlevels == 0 || max_positions == 0 || nframes == 0) return 0;
+  hipLaunchKernelGGL(k_cv24_cascade, dim3((max_positions + 255) / 256, nlevels, nframes), dim3(256), 0, st, args);
   return (int)hipGetLastError();
 }
 
