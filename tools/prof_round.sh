@@ -3,6 +3,8 @@
 #   bench.json            python bench.py (default flags)
 #   bench_c3.json / _c5   python bench.py --config 3 / 5 (BASELINE configs #3, #5)
 #   bench_2ranks.json     python bench.py --gpus 2 --backend gloo --share-gpu (rehearsal of the multi-rank path on one GPU)
+#   bench_cv24.json       python bench.py --semantics cv24 (the OpenCV-2.4 evaluation of the same call, 720p, alt)
+#   phase.txt             share of wave time per k_cascade phase (HC_PHASE build, if ugproj-detector_amd/libhip_cascade_PH.so exists)
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default command
 #   pmc_*                 separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ+LDS counters), no tracing mixed in
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -13,11 +15,15 @@ echo "bench done" > $O/progress.txt
 timeout -k 10 400 python bench.py --config 3 > $O/bench_c3.json 2> $O/bench_c3.err; echo "c3 rc=$?" >> $O/progress.txt
 timeout -k 10 600 python bench.py --config 5 --steps 10 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?" >> $O/progress.txt
 timeout -k 10 400 python bench.py --gpus 2 --backend gloo --share-gpu --batch 64 --steps 20 --cpu-sample 0 > $O/bench_2ranks.json 2> $O/bench_2ranks.err; echo "2ranks rc=$?" >> $O/progress.txt
+timeout -k 10 300 python bench.py --semantics cv24 --cpu-sample 0 > $O/bench_cv24.json 2> $O/bench_cv24.err; echo "cv24 rc=$?" >> $O/progress.txt
+if [ -f $R/ugproj-detector_amd/libhip_cascade_PH.so ]; then
+  HC_LIB_PATH=$R/ugproj-detector_amd/libhip_cascade_PH.so timeout -k 10 200 python bench.py --steps 3 --cpu-sample 0 --no-extra 2>&1 >/dev/null | grep "^\[phase" | tail -2 > $O/phase.txt
+fi
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --cpu-sample 0 > $O/trace.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --cpu-sample 0 --no-extra > $O/trace.log 2>&1 || exit 1
 cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
 echo "trace done" >> $O/progress.txt
-ARGS="$R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-timing-events"
+ARGS="$R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-timing-events --no-extra"
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch -- python3 $ARGS > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_write -- python3 $ARGS > $O/pmc_write.log 2>&1 || exit 1
 echo "traffic passes done" >> $O/progress.txt
