@@ -155,8 +155,8 @@ HC_API void hc_context_destroy(hc_context* ctx);
  * 0 (default): OpenCV >= 4, everything in this section as described.
  * 1: OpenCV 2.4.x (Appendix B; see hc_detect_multiscale_cv24 above) as a batched, device-resident path: its own scale
  *    loop and cvResize pyramid, f64 variance factors, then the same LDS-tiled band kernel with 2.4's node arithmetic
- *    for cascades whose stages form a chain (alt, alt2, default), the window-at-a-time kernel for a real stage tree
- *    (alt_tree).  Host or device frames, stage taps (HC_TAP_STAGES: stages passed, | 64 when accepted), raw candidates
+ *    for cascades whose stages form a chain (alt, alt2, default) and a preorder sweep of the stage tree on the same
+ *    tiles for alt_tree.  Host or device frames, stage taps (HC_TAP_STAGES: stages passed, | 64 when accepted), raw candidates
  *    and grouping (minNeighbors 0 = raw candidates) as 2.4 defines them.  Not available: shared prep passes, the
  *    detectFaces path, pyramid / integral taps of the >= 4 layout keep their meaning (HC_TAP_VNF is empty). */
 HC_API int  hc_context_set_semantics(hc_context* ctx, int semantics);

@@ -24,7 +24,112 @@ namespace casc_cv24 {
 #define HC_BODY_NO_LAUNCHERS
 #include "cascade_body.inc"
 #undef HC_INTW
+
+// ---- a real stage tree (haarcascade_frontalface_alt_tree: two branches below stage 4, the second tried when the first
+// fails) on the same LDS tiles.  Every window carries the index of the stage it is at.  A passing window goes to the
+// stage's first child, a failing one to the next sibling of the nearest ancestor-or-self that has one: in PREORDER of the
+// stage tree (a stage, its child subtree, then its next sibling -- tree_order, from the host) both targets come later, so
+// ONE sweep over that order visits every window at every stage of its path: the windows at stage s are gathered into a
+// list, evaluated lane = window with the 2.4 node arithmetic of eval_stage, and sent on to tree_pass[s] or tree_fail[s].
+// LDS: [ vnf f64 x TILE_WIN ][ list u16 x TILE_WIN ][ stage u8 x TILE_WIN ][ passed u8 x TILE_WIN ][ counter ][ tile ]
+constexpr int TREE_ACCEPT = 254, TREE_REJECT = 255;
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 8) void k_cv24_tree(CascadeArgs A) {
+  constexpr int ROWS = 16, TILE_WIN = ROWS * TILE_POS, NTHREADS = NW * 64;
+  extern __shared__ int32_t smem[];
+  double* vnf_t = (double*)smem;
+  uint16_t* list = (uint16_t*)(vnf_t + TILE_WIN);
+  uint8_t* at_stage = (uint8_t*)(list + TILE_WIN);
+  uint8_t* passed = at_stage + TILE_WIN;
+  int* counter = (int*)(passed + TILE_WIN);
+  int32_t* tile = (int32_t*)(counter + 2);
+  const WorkItem it = load_item(A.bands, blockIdx.y);
+  const HC_CONST DevLevel& L = as_const(A.levels)[it.level];
+  const HC_CONST DevStage* stages = as_const(A.stages);
+  const HC_CONST DevTree* trees = as_const(A.trees);
+  const HC_CONST DevNode* nodes = as_const(A.nodes);
+  const HC_CONST DevStageKinds* kinds = as_const(A.kinds);
+  const int frame = blockIdx.x;
+  const int ys = L.ystep;
+  const TileGeom G = A.g;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int gy0 = it.a, y0 = gy0 * ys, nx = L.nx, ny = L.ny;
+  const uint32_t* __restrict__ I = A.sum + (size_t)frame * A.int_stride + L.int_ofs;
+  const size_t grid_base = (size_t)frame * A.grid_stride + L.grid_ofs;
+  const double* __restrict__ vnf_g = A.vnf64 + grid_base;
+  const unsigned long long key_hi = ((unsigned long long)frame << 40) | ((unsigned long long)it.level << 32);
+  const unsigned long long lt_mask = lane ? ((1ull << lane) - 1ull) : 0ull;
+  for (int gx0 = 0; gx0 < nx; gx0 += TILE_POS) {
+    __syncthreads();
+    fill_tile<NW>(tile, I, L, G, ys, gx0 * ys, y0, wave, lane);
+    for (int pos = threadIdx.x; pos < TILE_WIN; pos += NTHREADS) {
+      const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
+      const bool valid = gy < ny && gx < nx;
+      vnf_t[pos] = valid ? vnf_g[(size_t)gy * nx + gx] : 0.0;
+      at_stage[pos] = valid ? 0 : (uint8_t)TREE_REJECT;
+      passed[pos] = 0;
+    }
+    for (int k = 0; k < A.nstages; k++) {
+      const int s = as_const(A.tree_order)[k];
+      if (threadIdx.x == 0) counter[k & 1] = 0;
+      __syncthreads();
+      // the windows that are at stage s -> list (wave-aggregated append)
+      for (int p0 = wave * 64; p0 < TILE_WIN; p0 += NTHREADS) {
+        const int pos = p0 + lane;
+        const bool mine = at_stage[pos] == s;
+        const unsigned long long m = __ballot(mine);
+        if (m) {
+          int off = 0;
+          if (lane == 0) off = atomicAdd(&counter[k & 1], __popcll(m));
+          off = __builtin_amdgcn_readfirstlane(off);
+          if (mine) list[off + __popcll(m & lt_mask)] = (uint16_t)pos;
+        }
+      }
+      __syncthreads();
+      const int n = counter[k & 1];
+      if (n == 0) continue;                                        // uniform
+      const int to_pass = as_const(A.tree_pass)[s], to_fail = as_const(A.tree_fail)[s];
+      for (int i0 = wave * 64; i0 < n; i0 += NTHREADS) {
+        const int i = i0 + lane;
+        const bool active = i < n;
+        const int pos = active ? list[i] : list[0];
+        const int base = (pos >> 6) * ys * G.pitch + (pos & 63);
+        const bool ok = eval_stage<false, NoSpec, 0>(tile, base, vnf_t[pos], s, stages, kinds, nodes, trees, A.leaves);
+        if (active) {
+          const int to = ok ? to_pass : to_fail;
+          at_stage[pos] = (uint8_t)to;
+          if (ok) passed[pos]++;
+          if (to == TREE_ACCEPT) {
+            const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
+            if (A.cand_cap) {
+              const unsigned int slot = atomicAdd(A.cand_count, 1u);
+              if (slot < A.cand_cap) A.cand[slot] = key_hi | ((unsigned long long)gy << 16) | (unsigned long long)gx;
+            }
+          }
+        }
+      }
+    }
+    if (A.taps) {
+      __syncthreads();
+      for (int pos = threadIdx.x; pos < TILE_WIN; pos += NTHREADS) {
+        const int gy = gy0 + (pos >> 6), gx = gx0 + (pos & 63);
+        if (gy < ny && gx < nx)
+          A.taps[grid_base + (size_t)gy * nx + gx] = (int8_t)(min((int)passed[pos], 63) | (at_stage[pos] == TREE_ACCEPT ? 64 : 0));
+      }
+    }
+  }
+}
 }  // namespace casc_cv24
+
+// stage tree of a stump cascade on the tiles (k_cv24_tree); lds_bytes: tile words * 4 + TILE_WIN * 12 + 8
+int launch_cv24_tree(hipStream_t st, int nframes, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
+  if (args.nbands == 0 || nframes == 0) return 0;
+  const dim3 grid(nframes, args.nbands), block(nwaves * 64);
+  if (nwaves == 4) hipLaunchKernelGGL((casc_cv24::k_cv24_tree<4>), grid, block, lds_bytes, st, args);
+  else if (nwaves == 8) hipLaunchKernelGGL((casc_cv24::k_cv24_tree<8>), grid, block, lds_bytes, st, args);
+  else return (int)hipErrorInvalidValue;
+  return (int)hipGetLastError();
+}
 
 // The production band shapes only: 16 grid rows, 4 wavefronts at scan step 1 and 8 at scan step 2, whole bands.
 int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {

@@ -33,6 +33,7 @@
 
 namespace hc {
 int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+int launch_cv24_tree(hipStream_t st, int nframes, int nwaves, size_t lds_bytes, const CascadeArgs& args);
 int launch_cv24_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items, const uint32_t* sum,
                          const uint32_t* sq, size_t int_stride, int norm_w, int norm_h, double inv_area, double* vnf, size_t grid_stride);
 }
@@ -172,6 +173,8 @@ struct hc_context {
   hc::Cv24Node* d_cvnodes = nullptr;
   hc::Cv24Tree* d_cvtrees = nullptr;
   hc::Cv24Stage* d_cvstages = nullptr;
+  uint8_t *d_tree_pass = nullptr, *d_tree_fail = nullptr, *d_tree_order = nullptr;   // stage tree on the tiles (k_cv24_tree)
+  bool cv_tree_tiled = false;
   // several cascades over the same frames (hc_context_configure_shared): the leader owns the pyramid integrals of
   // the union ladder, followers read them.  prep_seq counts the leader's enqueues; a follower scans each once.
   hc_context* leader = nullptr;
@@ -534,8 +537,9 @@ int plugin_load(const char* path) {
 
 void free_model_tables(hc_context* c) {
   void* ptrs[] = {c->d_nodes[0], c->d_nodes[1], c->d_nodes_sparse[0], c->d_nodes_sparse[1], c->d_stages, c->d_trees, c->d_leaves,
-                  c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages};
+                  c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages, c->d_tree_pass, c->d_tree_fail, c->d_tree_order};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  c->d_tree_pass = c->d_tree_fail = c->d_tree_order = nullptr;
   c->d_nodes[0] = c->d_nodes[1] = c->d_nodes_sparse[0] = c->d_nodes_sparse[1] = nullptr;
   c->d_stages = nullptr; c->d_trees = nullptr; c->d_leaves = nullptr; c->d_kinds = nullptr;
   c->d_cvnodes = nullptr; c->d_cvtrees = nullptr; c->d_cvstages = nullptr;
@@ -546,6 +550,8 @@ int upload_model(hc_context* c) {
   free_model_tables(c);
   const hc::Model& m = c->casc->model;
   const bool cv24 = c->semantics == 1;
+  c->cv_chain = true;
+  c->cv_tree_tiled = false;
   std::vector<hc::DevNode> nd[2];
   for (int k = 0; k < 2; k++) {
     const int ystep = k + 1;
@@ -675,6 +681,36 @@ int upload_model(hc_context* c) {
       int rc0 = hc::cv24_tree_tables(m, cn, ct, cs);
       if (rc0 != HC_OK) return rc0;
       if ((rc0 = dev_upload(&c->d_cvnodes, cn)) || (rc0 = dev_upload(&c->d_cvtrees, ct)) || (rc0 = dev_upload(&c->d_cvstages, cs))) return rc0;
+      // the same tree for the tiled kernel (stump cascades): per stage where a window goes when it passes (first child,
+      // or accepted) and when it fails (next sibling of the nearest ancestor-or-self that has one, or rejected)
+      c->cv_tree_tiled = m.is_stump() && cs.size() <= 250;
+      if (c->cv_tree_tiled) {
+        std::vector<uint8_t> tp(cs.size()), tf(cs.size());
+        for (size_t i = 0; i < cs.size(); i++) {
+          tp[i] = cs[i].child >= 0 ? (uint8_t)cs[i].child : (uint8_t)254;
+          int si = (int)i;
+          while (si >= 0 && cs[si].next < 0) si = cs[si].parent;
+          tf[i] = si >= 0 ? (uint8_t)cs[si].next : (uint8_t)255;
+        }
+        // preorder: a stage, its child subtree, then its next sibling (roots are chained through `next` as well)
+        std::vector<uint8_t> order;
+        std::vector<int> stack;
+        for (int root = 0; root >= 0 && root < (int)cs.size(); root = -1) stack.push_back(root);
+        std::vector<char> seen(cs.size(), 0);
+        while (!stack.empty()) {
+          const int v = stack.back();
+          stack.pop_back();
+          if (v < 0 || seen[v]) continue;
+          seen[v] = 1;
+          order.push_back((uint8_t)v);
+          if (cs[v].next >= 0) stack.push_back(cs[v].next);       // visited after the whole child subtree
+          if (cs[v].child >= 0) stack.push_back(cs[v].child);
+        }
+        for (size_t i = 0; i < cs.size(); i++)                      // stages no walk reaches: harmless, keep the table complete
+          if (!seen[i]) order.push_back((uint8_t)i);
+        if ((rc0 = dev_upload(&c->d_tree_pass, tp)) || (rc0 = dev_upload(&c->d_tree_fail, tf)) || (rc0 = dev_upload(&c->d_tree_order, order)))
+          return rc0;
+      }
     }
   }
   if (c->int_weights)
@@ -846,8 +882,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                       m.win_w - 2, m.win_h - 2, c->cv.inv_area, c->d_vnf64, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_cv24_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (timed) HIPCHK(hipEventRecord(c->ev[4], s));
-    if (c->semantics == 1 && !c->cv_chain) {
-      // a real stage tree (alt_tree): window-at-a-time evaluation that walks parent / next / child
+    if (c->semantics == 1 && !c->cv_chain && !c->cv_tree_tiled) {
+      // a real stage tree of a cascade the tiled tree kernel does not take: window-at-a-time evaluation that walks parent / next / child
       hc::Cv24Args T{};
       T.levels = c->d_cvlevels; T.sum = c->d_sum; T.sq = c->d_sq; T.int_stride = int_stride; T.grid_stride = grid_stride;
       T.stages = c->d_cvstages; T.trees = c->d_cvtrees; T.nodes = c->d_cvnodes; T.leaves = c->d_leaves; T.inv_area = c->cv.inv_area;
@@ -866,7 +902,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     int launches = 0;
     c->last_compiled = 0;
     for (int k = 1; k >= 0; k--) {      // ystep-2 levels (the largest) first
-      if (c->semantics == 1 && !c->cv_chain) break;           // done by the window-at-a-time kernel above
+      if (c->semantics == 1 && !c->cv_chain && !c->cv_tree_tiled) break;           // done by the window-at-a-time kernel above
       hc::CascadeArgs A{};
       A.sum = c->d_sum; A.int_stride = int_stride; A.vnf = c->d_vnf; A.vnf64 = c->d_vnf64; A.grid_stride = grid_stride;
       const bool seg = c->semantics == 0 && equiv <= c->seg_max_batch && c->n_seg_items[k] > 0;
@@ -885,7 +921,10 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.int_weights = c->int_weights ? 1 : 0;
       A.spec = c->spec_id;
       int compiled = 0;
-      if (c->semantics == 1)
+      A.tree_pass = c->d_tree_pass; A.tree_fail = c->d_tree_fail; A.tree_order = c->d_tree_order;
+      if (c->semantics == 1 && !c->cv_chain)
+        e = hc::launch_cv24_tree(side && k == 1 ? c->side_stream : s, nframes, c->band_waves[k], c->lds_bytes[k], A);
+      else if (c->semantics == 1)
         e = hc::launch_cascade_cv24(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), c->band_rows[k], c->band_waves[k],
                                     c->lds_bytes[k], A);
       else

@@ -34,6 +34,10 @@ struct CascadeArgs {
   unsigned int* cand_count;
   unsigned int cand_cap;
   int8_t* taps;               // nullable: per-position stage-pass counts
+  const uint8_t* tree_pass;   // OpenCV-2.4 stage tree (k_cv24_tree): stage a window goes to when it passes / fails stage s;
+  const uint8_t* tree_fail;   //   254 = accepted, 255 = rejected
+  const uint8_t* tree_order;  // the stages in preorder of the stage tree (a stage, its child subtree, then its next sibling): both
+                              //   targets of a stage come later in this order
   int int_weights;            // the node weight words hold int32 (w0 == -1 proven): run the exact-integer build
   int spec;                   // >= 1: id of the compiled early stages matching this cascade (spec_lookup), 0: none
 };
