@@ -20,8 +20,11 @@ import sys
 
 import numpy as np
 
+import os
+
 TILE_POS = 64
 GROUP = 2        # stumps whose corner reads are issued together
+DUP_READS = int(os.environ.get("HC_GEN_DUP_READS", "0"))   # experiments only: never set when the committed files are generated
 
 
 def load_hcc(path):
@@ -257,6 +260,9 @@ def main():
                     for gi, (_, lo, hi) in enumerate(consts):
                         L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
                     L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
+                    if s < DUP_READS:       # sensitivity probe (HC_GEN_DUP_READS): every corner of the first stages read twice
+                        for o in corner:
+                            L.append("      asm volatile(\"\" :: \"v\"(T(a, %d)));" % o)
                     L.append("      __builtin_amdgcn_sched_barrier(0);")
                     for gi, f in enumerate(feats):
                         L.append("      const int f%d = %s;" % (gi, f))
