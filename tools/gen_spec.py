@@ -12,7 +12,12 @@ geometry match, anything else runs the generic kernel.  Only stages whose f64 su
 of two-node trees (haarcascade_frontalface_alt2: a root, one of whose branches is a leaf) are compiled with both nodes of a
 tree evaluated and the leaf chosen by two selects.
 
-usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 band_rows_ystep2]
+usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 band_rows_ystep2] [--p16]
+
+--p16: the unit of the 16-bit-tile build of the kernel (cascade_body.inc HC_P16; scan step 1 only): corner offsets in
+2-byte entries, rect sums modulo 2^16, and for the row-form stages 0-1 a PAIR form that evaluates two adjacent windows per
+lane from 4-byte reads of entry pairs (even corner columns from copy A of the tile, odd ones from the shifted copy B).
+Refused when a rect of a compiled stage has more than 257 pixels.
 """
 import math
 import struct
@@ -132,9 +137,118 @@ def geom(win_w, win_h, ystep, band_rows):
     return 2 * half, half, rows
 
 
+PAIR_STAGES = 2   # --p16: stages with a pair form (the kernel's row-form stages)
+
+
+def emit_p16(L, m, nodes, first, nst, pitch, tree_terms, dwords, order):
+    """stage code of the 16-bit-tile build, scan step 1: T16(a, byte offset) = one entry (zero-extended), T2(a, byte offset) =
+    an aligned entry pair (hc_u16x2); `a` / `ab` = LDS byte address of the window origin in copy A / copy B."""
+    def off(dx, dy):
+        return (dy * pitch + dx) * 2
+
+    def rects(n):
+        out = []
+        for r in range(3):
+            x, y, w, h = [int(v) for v in n["r"][r]]
+            wt = int(n["w"][r])
+            if r == 2 and wt == 0:
+                continue
+            out.append((wt, [(x, y), (x + w, y), (x, y + h), (x + w, y + h)]))
+        return out
+
+    def feature1(n, corner):
+        terms = []
+        for r, (wt, cs) in enumerate(rects(n)):
+            c = [corner.setdefault(off(dx, dy), "c%d" % len(corner)) for dx, dy in cs]
+            rs = "((%s - %s - %s + %s) & 0xffff)" % tuple(c)
+            terms.append(rs if r == 0 else "__mul24(%d, %s)" % (wt, rs))
+        return " + ".join(terms[1:]) + " - " + terms[0]
+
+    def feature2(n, corner, sums):
+        """two windows: rect sums as hc_u16x2 (modulo 2^16 by construction), then one feature per window"""
+        names = []
+        for r, (wt, cs) in enumerate(rects(n)):
+            c = []
+            for dx, dy in cs:
+                key = ("A", off(dx, dy)) if dx % 2 == 0 else ("B", off(dx - 1, dy))
+                c.append(corner.setdefault(key, "p%d" % len(corner)))
+            nm = "s%d" % len(sums)
+            sums.append("const hc_u16x2 %s = %s - %s - %s + %s;" % ((nm,) + tuple(c)))
+            names.append((wt, nm))
+        def one(comp):
+            t = ["(int)%s.%s" % (nm, comp) if r == 0 else "__mul24(%d, (int)%s.%s)" % (wt, nm, comp) for r, (wt, nm) in enumerate(names)]
+            return " + ".join(t[1:]) + " - " + t[0]
+        return one("x"), one("y")
+
+    for s in range(nst):
+        thr = np.float32(np.float32(m["stages"]["thr"][s]) - np.float32(1e-5))
+        bsum = sum(tree_terms(t)[0] for t in range(first[s], first[s + 1]))
+        ks = order(nodes, list(range(first[s], first[s + 1])))
+        L.append("  static __device__ __forceinline__ bool stage%d_y1(int a, float vnf) {" % s)
+        L.append("    double acc = %s;" % float(bsum).hex())
+        for g0 in range(0, len(ks), GROUP):
+            grp = ks[g0:g0 + GROUP]
+            corner, feats, consts = {}, [], []
+            for k in grp:
+                feats.append(feature1(nodes[k], corner))
+                consts.append((f32bits(nodes[k]["thr"]),) + dwords(tree_terms(k)[1][0]))
+            L.append("    {")
+            for gi, (_, lo, hi) in enumerate(consts):
+                L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
+            L.append("      const int " + ", ".join("%s = T16(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
+            L.append("      __builtin_amdgcn_sched_barrier(0);")
+            for gi, f in enumerate(feats):
+                L.append("      const int f%d = %s;" % (gi, f))
+            for gi, (thrb, _, _) in enumerate(consts):
+                L.append("      A(acc, vnf, f%d, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
+            L.append("    }")
+        L.append("    return !(acc < (double)__uint_as_float(0x%08xu));" % f32bits(thr))
+        L.append("  }")
+        if s >= PAIR_STAGES:
+            continue
+        L.append("  static __device__ __forceinline__ void pair%d_y1(int a, int ab, float v0, float v1, bool& ok0, bool& ok1) {" % s)
+        L.append("    double acc0 = %s, acc1 = acc0;" % float(bsum).hex())
+        for g0 in range(0, len(ks), GROUP):
+            grp = ks[g0:g0 + GROUP]
+            corner, sums, feats, consts = {}, [], [], []
+            for k in grp:
+                feats.append(feature2(nodes[k], corner, sums))
+                consts.append((f32bits(nodes[k]["thr"]),) + dwords(tree_terms(k)[1][0]))
+            L.append("    {")
+            for gi, (_, lo, hi) in enumerate(consts):
+                L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
+            L.append("      const hc_u16x2 " + ", ".join("%s = T2(%s, %d)" % (nm, "a" if cp == "A" else "ab", o) for (cp, o), nm in corner.items()) + ";")
+            L.append("      __builtin_amdgcn_sched_barrier(0);")
+            for ln in sums:
+                L.append("      " + ln)
+            for gi, (fx, fy) in enumerate(feats):
+                L.append("      const int f%da = %s, f%db = %s;" % (gi, fx, gi, fy))
+            for gi, (thrb, _, _) in enumerate(consts):
+                L.append("      A(acc0, v0, f%da, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
+                L.append("      A(acc1, v1, f%db, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
+            L.append("    }")
+        L.append("    ok0 = !(acc0 < (double)__uint_as_float(0x%08xu));" % f32bits(thr))
+        L.append("    ok1 = !(acc1 < (double)__uint_as_float(0x%08xu));" % f32bits(thr))
+        L.append("  }")
+    L.append("  template <int YS> static __device__ __forceinline__ bool eval(int s, int a, float vnf) {")
+    L.append("    switch (s) {")
+    for s in range(nst):
+        L.append("      case %d: return stage%d_y1(a, vnf);" % (s, s))
+    L.append("      default: return false;")
+    L.append("    }")
+    L.append("  }")
+    L.append("  template <int YS> static __device__ __forceinline__ void eval_pair(int s, int a, int ab, float v0, float v1, bool& ok0, bool& ok1) {")
+    L.append("    if (s == 0) pair0_y1(a, ab, v0, v1, ok0, ok1);")
+    if nst > 1 and PAIR_STAGES > 1:
+        L.append("    else pair1_y1(a, ab, v0, v1, ok0, ok1);")
+    L.append("  }")
+
+
 def main():
-    path, tag, nst, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    band_rows = [int(sys.argv[5]), int(sys.argv[6])] if len(sys.argv) > 6 else [16, 16]
+    argv = [a for a in sys.argv if a != "--p16"]
+    p16 = len(argv) != len(sys.argv)
+    path, tag, nst, out = argv[1], argv[2], int(argv[3]), argv[4]
+    band_rows = [int(argv[5]), int(argv[6])] if len(argv) > 6 else [16, 16]
     m = load_hcc(path)
     tn = m["tree_nnodes"]
     if int(tn.max()) == 1:
@@ -189,6 +303,10 @@ def main():
         if not stage_exact_terms(s):
             nst = s
             break
+
+    def dwords(d):
+        bits = struct.unpack("<Q", struct.pack("<d", d))[0]
+        return bits & 0xffffffff, bits >> 32
     L = []
     L.append("// GENERATED by tools/gen_spec.py from %s -- do not edit.  Stages 0..%d of the cascade as straight-line code." % (path.split("/")[-1], nst - 1))
     L.append("// Included inside namespace hc::casc_int by csrc/spec_unit.inc, after cascade_body.inc's helpers.")
@@ -197,12 +315,25 @@ def main():
     L.append("  static constexpr int win_w = %d, win_h = %d, nstages = %d;" % (m["win_w"], m["win_h"], nst))
     L.append("  static constexpr bool is_tree = %s;   // two nodes per tree (the kernel's TREE instantiation)" % ("true" if is_tree else "false"))
     L.append("  static constexpr int band_rows1 = %d, band_rows2 = %d;" % (band_rows[0], band_rows[1]))
+    if p16:
+        if is_tree:
+            raise SystemExit("--p16: stump cascades only")
+        for s in range(nst):
+            for k in range(nfirst[first[s]], nfirst[first[s + 1]]):
+                for r in range(3):
+                    if int(nodes[k]["w"][r]) != 0 and int(nodes[k]["r"][r][2]) * int(nodes[k]["r"][r][3]) > 257:
+                        raise SystemExit("--p16: stage %d has a rect of more than 257 pixels" % s)
+        pitch16 = (geom(m["win_w"], m["win_h"], 1, band_rows[0])[0] + 1) & ~1
+        L.append("  static constexpr int pitch1 = %d, pitch2 = 0;   // LDS tile row pitch in 2-byte entries (scan step 1 only)" % pitch16)
+        L.append("  static constexpr bool p16 = true;")
+        L.append("  static constexpr int pair_stages = %d;" % min(PAIR_STAGES, nst))
+        emit_p16(L, m, nodes, first, nst, pitch16, tree_terms, dwords, order_for_sharing)
+        L.append("};")
+        open(out, "w").write("\n".join(L) + "\n")
+        print("%s: %d stages (16-bit tile, %d with a pair form), hash %016x" % (tag, nst, min(PAIR_STAGES, nst), model_hash(m)))
+        return
     L.append("  static constexpr int pitch1 = %d, pitch2 = %d;   // LDS tile row pitch (words) the offsets below assume" %
              (geom(m["win_w"], m["win_h"], 1, band_rows[0])[0], geom(m["win_w"], m["win_h"], 2, band_rows[1])[0]))
-
-    def dwords(d):
-        bits = struct.unpack("<Q", struct.pack("<d", d))[0]
-        return bits & 0xffffffff, bits >> 32
 
     for ys in (1, 2):
         pitch, half, _ = geom(m["win_w"], m["win_h"], ys, band_rows[ys - 1])

@@ -226,6 +226,15 @@ struct hc_context {
   hc::DevNode* d_nodes_sparse[2] = {nullptr, nullptr};   // the same records, every exact stage in bank-spreading order (sparse finish)
   bool int_weights = false;              // every node: w0 == -1, w1 / w2 integers, weighted rect sums below 2^24 (upload_model)
   int spec_id = 0;                       // compiled early stages matching this model (hc::spec_lookup), 0: none
+  // 16-bit-tile build of the scan-step-1 launch (cascade_body.inc HC_P16): its own tile geometry, node tables (2-byte
+  // entry offsets, rects of more than 257 pixels split in two) and compiled unit; whole-band launches only
+  bool p16 = false, allow_p16 = true;    // HC_P16=0: never
+  int spec_id_p16 = 0;
+  hc::TileGeom geom_p16 = {};
+  size_t lds_bytes_p16 = 0;
+  int tile_words_p16 = 0;
+  hc::DevNode *d_nodes_p16 = nullptr, *d_nodes_sparse_p16 = nullptr;
+  hc::DevStageKinds* d_kinds_p16 = nullptr;
   int last_compiled = 0;                 // stages that ran as compiled code in EVERY cascade launch of the last enqueued batch
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;
@@ -333,10 +342,11 @@ hc::TileGeom make_geom(const hc::Model& m, int ystep, int band_rows) {
   return g;
 }
 
-void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vector<hc::DevNode>& out) {
+void build_nodes(const hc::Model& m, const hc::TileGeom& g, int ystep, std::vector<hc::DevNode>& out, bool p16 = false) {
   out.clear();
   out.reserve(m.nodes.size());
   auto word = [&](int dx, int dy) {
+    if (p16) return (uint16_t)((dy * g.pitch + dx) * 2);   // 16-bit tile (scan step 1): 2-byte entries
     const int col = ystep == 1 ? dx : ((dx & 1) * g.half + (dx >> 1));
 #ifndef HC_OFF_WORDS
     return (uint16_t)((dy * g.pitch + col) * 4);   // byte offsets: the kernel adds them to a byte base (kernels.hip hc_corner_addr)
@@ -537,12 +547,86 @@ int plugin_load(const char* path) {
 
 void free_model_tables(hc_context* c) {
   void* ptrs[] = {c->d_nodes[0], c->d_nodes[1], c->d_nodes_sparse[0], c->d_nodes_sparse[1], c->d_stages, c->d_trees, c->d_leaves,
-                  c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages, c->d_tree_pass, c->d_tree_fail, c->d_tree_order};
+                  c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages, c->d_tree_pass, c->d_tree_fail, c->d_tree_order,
+                  c->d_nodes_p16, c->d_nodes_sparse_p16, c->d_kinds_p16};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   c->d_tree_pass = c->d_tree_fail = c->d_tree_order = nullptr;
+  c->d_nodes_p16 = c->d_nodes_sparse_p16 = nullptr; c->d_kinds_p16 = nullptr; c->p16 = false; c->spec_id_p16 = 0;
   c->d_nodes[0] = c->d_nodes[1] = c->d_nodes_sparse[0] = c->d_nodes_sparse[1] = nullptr;
   c->d_stages = nullptr; c->d_trees = nullptr; c->d_leaves = nullptr; c->d_kinds = nullptr;
   c->d_cvnodes = nullptr; c->d_cvtrees = nullptr; c->d_cvstages = nullptr;
+}
+
+// every corner offset of the 16-bit tile fits the 16-bit offset fields (trivially, for windows this build accepts)
+bool node_kinds_fit_p16(const hc::Model& m) { return m.win_w <= 40 && m.win_h <= 40; }
+
+// The cascade with every rect of more than 257 pixels cut into two halves (same weight; the second half takes the
+// node's free third slot): rect sums modulo 2^16 are then exact for every rect, and the feature value -- an integer
+// expression, weights_are_small_integers -- is unchanged.  False when some node has no free slot or a half is still too big.
+bool p16_model(const hc::Model& m, hc::Model& out) {
+  out = m;
+  for (hc::ModelNode& n : out.nodes) {
+    int big = -1;
+    for (int r = 0; r < 3; r++)
+      if (n.weight[r] != 0.f && n.rect[r][2] * n.rect[r][3] > 257) { if (big >= 0) return false; big = r; }
+    if (big < 0) continue;
+    if (n.weight[2] != 0.f || big == 2) return false;
+    const int x = n.rect[big][0], y = n.rect[big][1], w = n.rect[big][2], h = n.rect[big][3];
+    if (h >= w) {
+      const int h1 = h / 2;
+      n.rect[big][3] = (int8_t)h1;
+      n.rect[2][0] = (int8_t)x; n.rect[2][1] = (int8_t)(y + h1); n.rect[2][2] = (int8_t)w; n.rect[2][3] = (int8_t)(h - h1);
+    } else {
+      const int w1 = w / 2;
+      n.rect[big][2] = (int8_t)w1;
+      n.rect[2][0] = (int8_t)(x + w1); n.rect[2][1] = (int8_t)y; n.rect[2][2] = (int8_t)(w - w1); n.rect[2][3] = (int8_t)h;
+    }
+    n.weight[2] = n.weight[big];
+    if (n.rect[big][2] * n.rect[big][3] > 257 || n.rect[2][2] * n.rect[2][3] > 257) return false;
+  }
+  return true;
+}
+
+// Node tables of the 16-bit-tile build (scan step 1) from the split model: same stages, same leaf words, same ordering
+// rules (kind groups, bank-spreading order of the sparse copy) as the standard tables below.
+int upload_p16_tables(hc_context* c, const hc::Model& m16, const std::vector<hc::DevStage>& st) {
+  std::vector<hc::DevNode> nd;
+  build_nodes(m16, c->geom_p16, 1, nd, true);
+  std::vector<hc::DevStageKinds> kinds;
+  for (size_t si = 0; si < m16.stages.size(); si++) {
+    const hc::ModelStage& s = m16.stages[si];
+    const int first = st[si].first;
+    for (int i = 0; i < s.ntrees; i++) {
+      const hc::ModelTree& t = m16.trees[s.first_tree + i];
+      const double diff = (double)m16.leaves[t.first_leaf] - (double)m16.leaves[t.first_leaf + 1];
+      uint64_t bits;
+      memcpy(&bits, &diff, 8);
+      nd[t.first_node].a = (uint32_t)bits;
+      nd[t.first_node].b = (uint32_t)(bits >> 32);
+    }
+    std::vector<int> order(s.ntrees);
+    for (int i = 0; i < s.ntrees; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return node_kind(m16.nodes[first + x]) < node_kind(m16.nodes[first + y]); });
+    std::vector<hc::DevNode> tmp(s.ntrees);
+    hc::DevStageKinds kd{};
+    int cnt[hc::NK_COUNT] = {0};
+    for (int i = 0; i < s.ntrees; i++) { tmp[i] = nd[first + order[i]]; cnt[node_kind(m16.nodes[first + i])]++; }
+    std::copy(tmp.begin(), tmp.end(), nd.begin() + first);
+    int acc = 0;
+    for (int k2 = 0; k2 < hc::NK_COUNT; k2++) { acc += cnt[k2]; kd.end[k2] = (uint16_t)acc; }
+    kinds.push_back(kd);
+  }
+  for (hc::DevNode& d : nd)
+    for (int k = 0; k < 3; k++) {
+      const int32_t wi = (int32_t)d.w[k];
+      memcpy(&d.w[k], &wi, 4);
+    }
+  std::vector<hc::DevNode> ns = nd;
+  if (c->bank_order)
+    for (const hc::DevStage& d : st) order_stage_for_banks(ns, d.first, d.count);
+  int rc;
+  if ((rc = dev_upload(&c->d_nodes_p16, nd)) || (rc = dev_upload(&c->d_nodes_sparse_p16, ns)) || (rc = dev_upload(&c->d_kinds_p16, kinds))) return rc;
+  return HC_OK;
 }
 
 int upload_model(hc_context* c) {
@@ -739,6 +823,27 @@ int upload_model(hc_context* c) {
   if (m.is_stump() && (rc = dev_upload(&c->d_kinds, kinds))) return rc;
   if ((rc = dev_upload(&c->d_trees, tr))) return rc;
   if ((rc = dev_upload(&c->d_leaves, m.leaves))) return rc;
+  // ---- 16-bit-tile build of the scan-step-1 launch, when the cascade and the launch shape qualify
+  if (!cv24 && c->allow_p16 && c->allow_spec && c->int_weights && m.is_stump() && c->band_rows[0] == 16 && c->band_waves[0] == 4 &&
+      c->row_stages <= 2 && !st.empty() && st[0].exact == 2) {
+    int pst = 0;
+    const int id = hc::spec_lookup(model_hash(m), m.win_w, m.win_h, &pst, true);
+    hc::Model m16;
+    if (id > 0 && p16_model(m, m16)) {
+      hc::TileGeom g = make_geom(m, 1, 16);
+      g.pitch = (g.cols + 1) & ~1;
+      const size_t tile_bytes = ((size_t)g.pitch * g.rows * 2 + 7) & ~(size_t)7;
+      const size_t fixed = (size_t)16 * hc::TILE_POS * (4 + 6 + 2) + 264;  // vnf | copy B (6 KB; the list later) | bank matrix | 64 counters + ticket
+      if (tile_bytes <= (size_t)16 * hc::TILE_POS * 6 && node_kinds_fit_p16(m16)) {
+        c->geom_p16 = g;
+        c->tile_words_p16 = (int)(tile_bytes / 4);
+        c->lds_bytes_p16 = fixed + tile_bytes;
+        if ((rc = upload_p16_tables(c, m16, st))) return rc;
+        c->spec_id_p16 = id;
+        c->p16 = true;
+      }
+    }
+  }
   return HC_OK;
 }
 
@@ -910,8 +1015,10 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
       A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
       A.nodes = c->d_nodes[k]; A.nodes_sparse = c->d_nodes_sparse[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
+      const bool p16 = k == 0 && c->p16 && !seg && c->semantics == 0 && c->debug_max_stages == 0;
+      if (p16) { A.nodes = c->d_nodes_p16; A.nodes_sparse = c->d_nodes_sparse_p16; A.kinds = c->d_kinds_p16; }
       if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
-      A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = c->geom[k]; A.tile_words = c->tile_words[k];
+      A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = p16 ? c->geom_p16 : c->geom[k]; A.tile_words = p16 ? c->tile_words_p16 : c->tile_words[k];
       A.sparse_max = c->sparse_max;
       A.row_stages = c->row_stages;
       A.cand = c->d_cand; A.cand_count = c->d_count;
@@ -919,7 +1026,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       if (A.nstages < (int)m.stages.size()) A.cand_cap = 0;   // truncated cascade (timing experiments): emit nothing
       A.taps = c->taps_enabled ? c->d_taps : nullptr;
       A.int_weights = c->int_weights ? 1 : 0;
-      A.spec = c->spec_id;
+      A.spec = p16 ? c->spec_id_p16 : c->spec_id;
       int compiled = 0;
       A.tree_pass = c->d_tree_pass; A.tree_fail = c->d_tree_fail; A.tree_order = c->d_tree_order;
       if (c->semantics == 1 && !c->cv_chain)
@@ -929,7 +1036,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                     c->lds_bytes[k], A);
       else
       e = hc::launch_cascade(side && k == 1 ? c->side_stream : s, nframes, !m.is_stump(), seg, c->band_rows[k],
-                             c->band_waves[k], c->lds_bytes[k], A, &compiled);
+                             c->band_waves[k], p16 ? c->lds_bytes_p16 : c->lds_bytes[k], A, &compiled);
       if (A.nbands > 0) c->last_compiled = launches++ == 0 ? compiled : std::min(c->last_compiled, compiled);
       if (e) return set_err(HC_ERR_HIP, std::string("k_cascade launch: ") + hipGetErrorString((hipError_t)e));
     }
@@ -1070,6 +1177,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_PAIR_FORM")) ctx->pair_form = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_P16")) ctx->allow_p16 = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_BANK_ORDER")) ctx->bank_order = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_FUSED_MIN_BATCH")) ctx->fused_min_batch = atof(e_);
   if (const char* e_ = getenv("HC_SIDE_MAX_BATCH")) ctx->side_max_batch = std::max(0, atoi(e_));

@@ -49,13 +49,14 @@ struct SpecUnit {
   bool tree;                 // the cascade has two nodes per tree (k_cascade's TREE instantiation)
   // 0 / hipError_t, or -1 when the unit has no kernel for this launch shape (the generic kernel runs then)
   int (*launch)(hipStream_t st, int nframes, bool segments, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+  bool p16;                  // unit of the 16-bit-tile build (cascade_body.inc HC_P16): scan step 1, whole bands, its own node tables
 };
 // id (>= 1) of the unit matching a model, 0 if none; *nstages (nullable) = stages it compiles
-int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages);
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16 = false);
 // adds a unit that was not linked into the library (hc_spec_plugin_load); the object must outlive the process' use of it
 int spec_register(const SpecUnit* u);
 // layout check between the library and a plug-in built from another checkout of these sources
-constexpr int SPEC_PLUGIN_ABI = 4 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
+constexpr int SPEC_PLUGIN_ABI = 5 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
 
 // YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
 struct SkinBounds { int32_t lo[3], hi[3]; };

@@ -541,18 +541,18 @@ int spec_register(const SpecUnit* u) {
   if (!u || !u->launch || u->nstages <= 0) return -1;
   std::lock_guard<std::mutex> l(g_spec_mu);
   for (const SpecUnit* e : g_spec_extra)
-    if (e->hash == u->hash && e->win_w == u->win_w && e->win_h == u->win_h) return 0;     // already there
+    if (e->hash == u->hash && e->win_w == u->win_w && e->win_h == u->win_h && e->p16 == u->p16) return 0;     // already there
   g_spec_extra.push_back(u);
   return 0;
 }
 
-int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages) {
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16) {
   constexpr int nb = (int)(sizeof(spec_units) / sizeof(spec_units[0]));
   int nextra;
   { std::lock_guard<std::mutex> l(g_spec_mu); nextra = (int)g_spec_extra.size(); }
   for (int id = 1; id <= nb + nextra; id++) {
     const SpecUnit* u = spec_unit_by_id(id);
-    if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h) {
+    if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h && u->p16 == p16) {
       if (nstages) *nstages = u->nstages;
       return id;
     }
@@ -657,6 +657,7 @@ int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int ro
       if (compiled) *compiled = unit->nstages;
       return rc;
     }
+    if (unit->p16) return (int)hipErrorInvalidValue;   // the arguments are in that build's own formats: no other kernel may take them
   }
   return args.int_weights ? casc_int::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args)
                           : casc_f32::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args);
