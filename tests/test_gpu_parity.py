@@ -14,16 +14,21 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["policy", "fused"])
+@pytest.fixture(autouse=True, params=["policy", "fused", "wholeband"])
 def prep_route(request, monkeypatch):
-    """Every test of this module runs twice: under the library's own batch-size policy (no environment knob:
+    """Every test of this module runs three times: under the library's own batch-size policy (no environment knob:
     small batches take the three parallel prep kernels, band segments and the side stream; large ones the fused
-    k_pyramid_integral and whole bands) and with the fused prep kernel pinned (the throughput route, which the
-    mostly single-frame batches here would otherwise never reach).  Tests that set HC_FUSED_PREP themselves
-    override the pin."""
-    monkeypatch.delenv("HC_FUSED_PREP", raising=False)
-    if request.param == "fused":
+    k_pyramid_integral and whole bands), with the fused prep kernel pinned (the throughput route, which the
+    mostly single-frame batches here would otherwise never reach), and with whole-band cascade launches pinned
+    as well -- the instantiations a full batch runs, among them the 16-bit-tile build (HC_P16) that
+    haarcascade_frontalface_alt takes for its scan-step-1 levels.  Tests that set a knob themselves override the pin."""
+    for k in ("HC_FUSED_PREP", "HC_SEG_MAX_BATCH", "HC_SIDE_MAX_BATCH"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param != "policy":
         monkeypatch.setenv("HC_FUSED_PREP", "1")
+    if request.param == "wholeband":
+        monkeypatch.setenv("HC_SEG_MAX_BATCH", "0")
+        monkeypatch.setenv("HC_SIDE_MAX_BATCH", "0")
     return request.param
 
 
@@ -897,3 +902,32 @@ def test_retrained_cascade_runs_its_plugin_stages(pkg, oracle, synth):
         pkg.load_spec_plugin(so)
     assert run(pkg.Cascade(hcc)) == 8                       # compiled stages from the plug-in
     assert np.array_equal(pkg.Cascade(hcc).detect_multiscale(frames[0], 1.1, 2, 0, (30, 30)), wantb[0])
+
+
+def test_p16_build_and_standard_build_agree(pkg, oracle, synth, monkeypatch):
+    """haarcascade_frontalface_alt qualifies for the 16-bit-tile build of the scan-step-1 launch (two windows per lane in
+    the row-form stages, rects of more than 257 pixels cut in two): 20 frames of 720p, all families, as whole bands --
+    stage taps of every level of three frames, raw candidates and boxes of all, with the build on (default) and off."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    kinds = ["planted", "texture", "noise"]
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, 720, 1280, first=700 + i)[0] for i in range(20)])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(lambda fr: oc.detect(fr, 1.1, 2, (30, 30), (0, 0), want_taps=True), frames))
+    for on in ("1", "0"):
+        monkeypatch.setenv("HC_P16", on)
+        ctx = pkg.Context(casc)
+        ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=20, cand_capacity=1 << 13)
+        for taps in (True, False):
+            ctx.enable_stage_taps(taps)
+            got = ctx.detect_host(frames)
+            raws = ctx.raw_candidates(20)
+            for f in range(20):
+                grouped, raw, otaps = want[f]
+                if taps and f in (0, 7, 14):
+                    for li in range(len(ctx.levels())):
+                        assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (on, f, li)
+                assert np.array_equal(raws[f], raw), (on, taps, f)
+                assert np.array_equal(got[f], grouped), (on, taps, f)
+        ctx.close()

@@ -18,3 +18,5 @@ print("%-12s fps=%.0f ms/step=%.3f k_cascade=%.3f prep=%.3f parity=%s" % ("$labe
 PY
 }
 for rep in 1 2; do run p16_$rep HC_P16=1; run std_$rep HC_P16=0; done
+run p16_rows3 HC_LIB_PATH=$PWD/ugproj-detector_amd/libhip_cascade_ps3.so HC_ROW_STAGES=3
+run p16_rows1 HC_ROW_STAGES=1

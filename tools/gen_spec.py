@@ -137,7 +137,7 @@ def geom(win_w, win_h, ystep, band_rows):
     return 2 * half, half, rows
 
 
-PAIR_STAGES = 2   # --p16: stages with a pair form (the kernel's row-form stages)
+PAIR_STAGES = int(os.environ.get("HC_GEN_PAIR_STAGES", "2"))   # --p16: stages with a pair form (the kernel's row-form stages)
 
 
 def emit_p16(L, m, nodes, first, nst, pitch, tree_terms, dwords, order):
@@ -238,9 +238,11 @@ def emit_p16(L, m, nodes, first, nst, pitch, tree_terms, dwords, order):
     L.append("    }")
     L.append("  }")
     L.append("  template <int YS> static __device__ __forceinline__ void eval_pair(int s, int a, int ab, float v0, float v1, bool& ok0, bool& ok1) {")
-    L.append("    if (s == 0) pair0_y1(a, ab, v0, v1, ok0, ok1);")
-    if nst > 1 and PAIR_STAGES > 1:
-        L.append("    else pair1_y1(a, ab, v0, v1, ok0, ok1);")
+    L.append("    switch (s) {")
+    for s in range(min(PAIR_STAGES, nst)):
+        L.append("      case %d: pair%d_y1(a, ab, v0, v1, ok0, ok1); break;" % (s, s))
+    L.append("      default: ok0 = ok1 = false;")
+    L.append("    }")
     L.append("  }")
 
 
