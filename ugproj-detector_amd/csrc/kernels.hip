@@ -288,6 +288,31 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
   int ph = 0;
   for (int x = threadIdx.x; x < lds_pitch; x += PI_THREADS) xt_s[x] = x < w ? xtab[L.xtab_ofs + x] : 0u;
   __syncthreads();
+  // The two source rows of a wavefront's NEXT destination row are requested at the end of its phase 1 and wait in
+  // registers through phases 2 and 3 (HC_PI_PREFETCH pieces of 256 bytes per row; rows of up to 1280 pixels are covered
+  // entirely): the chunk no longer starts with an exposed round trip to L2 / HBM.
+#ifndef HC_PI_PREFETCH
+#define HC_PI_PREFETCH 5
+#endif
+  constexpr int NPF = (NH > 0 && CMAX == 2) ? HC_PI_PREFETCH : 0;
+  uint32_t pfa[NPF > 0 ? NPF : 1], pfb[NPF > 0 ? NPF : 1];
+  int pf_dy = -1;                                                  // destination row the registers hold the sources of
+  auto prefetch = [&](int dy) {
+    if (NPF == 0 || !dwords || dy >= h) return;
+    const uint32_t yt = yt_l[dy];
+    const int oy = yt >> 9, oy1 = min(oy + 1, rows - 1);
+    const uint32_t* g0 = (const uint32_t*)(src + (size_t)oy * row_step);
+    const uint32_t* g1 = (const uint32_t*)(src + (size_t)oy1 * row_step);
+    const int nd = (cols + 3) >> 2;
+#pragma unroll
+    for (int u = 0; u < NPF; u++) {
+      const int i = lane + 64 * u;
+      pfa[u] = i < nd ? g0[i] : 0u;
+      pfb[u] = i < nd ? g1[i] : 0u;
+    }
+    pf_dy = dy;
+  };
+  prefetch(wave);
 
   for (int y0 = 0; y0 < h; y0 += R) {
     const int nr = min(R, h - y0);
@@ -300,9 +325,18 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
       const uint8_t* g1 = src + (size_t)oy1 * row_step;
       if (dwords) {
         const int nd = (cols + 3) >> 2;                 // src_pitch is a multiple of 4 >= cols; row_step >= cols
+        int i_first = lane;
+        if (NPF > 0 && pf_dy == dy) {                   // the first NPF pieces were requested a chunk ago
+#pragma unroll
+          for (int u = 0; u < NPF; u++) {
+            const int i = lane + 64 * u;
+            if (i < nd) { ((uint32_t*)sr0)[i] = pfa[u]; ((uint32_t*)sr1)[i] = pfb[u]; }
+          }
+          i_first = lane + 64 * NPF;
+        }
         // four pieces of both rows per trip, all eight loads requested before the first LDS store (written as
         // load -> store per piece the compiler waits for every load separately: ten serial round trips per 1280-pixel row)
-        for (int i0 = lane; i0 < nd; i0 += 64 * 4) {
+        for (int i0 = i_first; i0 < nd; i0 += 64 * 4) {
           uint32_t a[4], b[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
@@ -366,6 +400,7 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
         carry_s += (uint32_t)__builtin_amdgcn_readlane((int)ts, 63);
         carry_q += (uint32_t)__builtin_amdgcn_readlane((int)tq, 63);
       }
+      if (r + PI_THREADS / 64 >= nr) prefetch(dy + R);       // this wavefront's row of the next chunk (R rows per chunk, one per wavefront)
     }
     __syncthreads();
     {
