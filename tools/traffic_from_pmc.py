@@ -6,6 +6,7 @@ FETCH_SIZE reports exactly half of the bytes of a streaming read (TCC_EA0_RDREQ 
 reports as roofline.traffic (per launch of frames_per_launch frames, scaled to its own batch size; the two
 k_cascade launches of a batch are summed).  usage: traffic_from_pmc.py <pmc dir> <out.json> [frames per launch]"""
 import collections
+import re
 import csv
 import glob
 import json
@@ -17,7 +18,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hc::", "").replace("casc_int::", "").replace("casc_f32::", "").split("<")[0]
+            k = re.sub(r"casc_\w+::", "", r["Kernel_Name"].split("(")[0].replace("void ", "").replace("hc::", "")).split("<")[0]
             acc[k][r["Counter_Name"] + "|" + r["Kernel_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in acc.items():
