@@ -133,6 +133,51 @@ def test_shared_prep_four_cascades_2160p(pkg, oracle, synth):
         c.close()
 
 
+def test_wait_does_not_wait_for_the_next_slot(pkg, oracle, synth):
+    """Two pipeline slots of a two-cascade shared pass = four contexts on one stream (bench.py's layout for BASELINE
+    config #3).  The wait for slot A's results must return when A's kernels are done, not when slot B's batch -- enqueued
+    behind it -- has drained as well: the runtime maps the streams of four contexts onto shared hardware queues, where a
+    stream / event wait returns a whole batch late, so results are published to host memory by the batch's own last
+    kernel and polled for (hc_api.cpp wait_published).  Same frames in both slots, so B takes as long as A."""
+    import time
+    import torch
+    B = 24
+    frames = np.stack([synth.make_frames("planted", 1, 720, 1280, first=700 + i)[0] for i in range(B)])
+    d_frames = torch.from_numpy(frames).cuda()
+    stream = torch.cuda.Stream()
+    cascs = [pkg.Cascade(oracle.cascade_path(n)) for n in ("alt2", "default")]
+    slots = []
+    for _ in range(2):
+        cs = [pkg.Context(c, device=0, stream=stream.cuda_stream) for c in cascs]
+        pkg.configure_shared(cs, 720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 14)
+        slots.append(cs)
+
+    def enqueue(slot):
+        for c in slot:
+            c.enqueue_device(d_frames.data_ptr(), B)
+
+    first = None
+    for rep in range(3):                                      # first repetition: allocations, code objects
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enqueue(slots[0]); enqueue(slots[1])
+        got_a = [c.wait(B) for c in slots[0]]
+        t1 = time.perf_counter()
+        got_b = [c.wait(B) for c in slots[1]]
+        t2 = time.perf_counter()
+        if first is None:
+            first = got_a
+        for x, y in zip(got_a + got_b, first + first):
+            assert all(np.array_equal(p, q) for p, q in zip(x, y))
+    assert (t2 - t1) > 0.25 * (t2 - t0), "slot A's wait returned only when slot B was done: %.2f ms of %.2f ms" % (
+        1e3 * (t1 - t0), 1e3 * (t2 - t0))
+    oc = oracle.OracleCascade(oracle.cascade_path("alt2"))
+    assert np.array_equal(first[0][3], oc.detect(frames[3], 1.1, 2, (30, 30), (0, 0))[0])
+    for cs in slots:
+        for c in cs:
+            c.close()
+
+
 def test_1080p_batch_two_cascades(pkg, oracle, synth):
     """BASELINE config #3 with a batch > 1: 8 distinct 1920x1080 frames (18 720p-equivalents: fused prep and whole
     bands by policy) through alt2 and default; stage counts of two frames, raw candidates and boxes of all."""

@@ -154,6 +154,17 @@ struct hc_context {
   bool own_stream = false;
   hipStream_t copy_stream = nullptr;   // D2H of results: never queues behind a later batch on `stream`
   hipEvent_t ev_done = nullptr;        // recorded on `stream` after the last kernel of a batch
+  // Recorded on copy_stream behind every device-to-host copy the host then needs.  The host waits for THIS EVENT, never
+  // for the stream: the runtime multiplexes streams onto a few hardware queues (four by default), a stream
+  // synchronisation places a marker at the tail of the hardware queue, and with four or more contexts alive the queue of
+  // one context's copy stream is also the queue of another's -- whose copy waits for a batch that is still running.
+  // Measured on a two-cascade shared pass (two pipeline slots = four contexts): every wait returned one whole batch
+  // late, the software pipeline ran one deep and the GPU idled 4 ms of every 41 ms step.
+  hipEvent_t ev_copied = nullptr;      // (now only the skin filter's box sums; a batch's results are published, see h_pub)
+  // {sequence number, raw-candidate count} in coherent page-locked host memory, written by the batch's last kernel
+  // (k_publish_flag); the candidates themselves arrive in h_cand the same way.  wait_core polls the sequence word.
+  unsigned int* h_pub = nullptr;
+  unsigned int pub_seq = 0;
   hipStream_t side_stream = nullptr;   // small batches: the ystep-2 cascade launch runs beside the ystep-1 launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int side_max_batch = 8;              // ... up to this many frames (a full batch fills the chip with one launch)
@@ -244,7 +255,6 @@ struct hc_context {
   unsigned int* d_count = nullptr;
   // pinned host
   unsigned long long* h_cand = nullptr;
-  unsigned int* h_count = nullptr;
 
   // FaceDetector::detectFaces path (reference src/tracker/detector.cc:10-43)
   bool faces_enabled = false, faces_pending = false;
@@ -279,6 +289,7 @@ struct hc_context {
   bool rerun_caller_frames = false;
   const void* prep_src = nullptr;        // leader of a shared pass: the frame pointer its caller passed for the current batch
   bool taps_enabled = false, timing_enabled = false, timed_last = false;
+  bool sq_valid = true;           // the last batch left the squares' integral in d_sq (the fused prep kernel keeps it in LDS unless a tap asks)
   hipEvent_t ev[HC_NKERNELS + 1] = {};
   float last_ms[HC_NKERNELS] = {};
   std::vector<hc_rect> last_raw;
@@ -310,8 +321,8 @@ struct hc_context {
     d_seg_items[0] = d_seg_items[1] = nullptr;
     d_cand = nullptr; d_count = nullptr;
     if (h_cand) (void)hipHostFree(h_cand);
-    if (h_count) (void)hipHostFree(h_count);
-    h_cand = nullptr; h_count = nullptr;
+    if (h_pub) (void)hipHostFree(h_pub);
+    h_cand = nullptr; h_pub = nullptr; pub_seq = 0;
     if (d_src_bgr) (void)hipFree(d_src_bgr);
     d_src_bgr = nullptr; src_rows = src_cols = 0;
     void* cptrs[] = {d_vnf64, d_cvlevels, d_cvtab_ofs, d_cvtab_a0, d_cvtab_a1};
@@ -930,6 +941,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (c->taps_enabled) HIPCHK(hipMemsetAsync(c->d_taps, 0xFE, grid_stride * nframes, s));
     int e;
     bool fused_variance = false;
+    c->sq_valid = true;
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
     // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
     const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
@@ -951,8 +963,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
     } else if (use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty())) {
-      int max_w = 0;
-      for (const hc::DevLevel& L : P.levels) max_w = std::max(max_w, L.w);
+      int max_w = 0, max_nx = 0;
+      for (const hc::DevLevel& L : P.levels) { max_w = std::max(max_w, L.w); max_nx = std::max(max_nx, L.nx); }
       // the pyramid bytes only exist as a debug tap in this mode
       // a context on its own gets its variance factors from the same kernel (no k_variance launch, no second pass
       // over the integrals); a shared prep pass serves cascades with different windows, which run k_variance each
@@ -960,7 +972,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       if ((e = hc::launch_pyramid_integral(s, nframes, (int)P.levels.size(), max_w, d_frames, frame_stride, row_step,
                                            P.rows, P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq,
                                            int_stride, c->taps_enabled ? c->d_pyr : nullptr, pyr_stride,
-                                           fused_variance ? c->d_vnf : nullptr, grid_stride, m.win_w - 2, m.win_h - 2)))
+                                           fused_variance ? c->d_vnf : nullptr, grid_stride, m.win_w - 2, m.win_h - 2, max_nx,
+                                           c->taps_enabled, &c->sq_valid)))
         return set_err(HC_ERR_HIP, std::string("k_pyramid_integral launch: ") + hipGetErrorString((hipError_t)e));
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
     } else {
@@ -1001,6 +1014,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     // the two launches (independent: different levels) then run side by side on two streams.
     const bool side = equiv <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
     if (side) {
+      if (!c->side_stream) HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
@@ -1046,12 +1060,15 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     }
     if (timed) HIPCHK(hipEventRecord(c->ev[5], s));
   }
-  // results travel on the side stream, ordered after this batch only (not after whatever the
-  // caller enqueues next on `stream`, e.g. the next batch of a software pipeline)
+  // Results: the batch's own last kernels store the candidates and {count, sequence number} in page-locked host memory;
+  // the host polls the sequence word.  No copy command, no wait on a stream or event of the runtime: those return when
+  // the hardware queue they were mapped to has drained, and with several contexts alive that queue also carries another
+  // context's pending work -- a software pipeline then runs one batch deep (see ev_copied).
+  if (int e = hc::launch_publish(s, c->d_count, c->d_cand, (unsigned int)std::min<size_t>(c->cand_cap, 0xffffffffu), c->h_cand, c->h_pub,
+                                 ++c->pub_seq))
+    return set_err(HC_ERR_HIP, std::string("k_publish launch: ") + hipGetErrorString((hipError_t)e));
   HIPCHK(hipEventRecord(c->ev_done, s));
   if (c->leader) c->scan_in_flight = true;
-  HIPCHK(hipStreamWaitEvent(c->copy_stream, c->ev_done, 0));
-  HIPCHK(hipMemcpyAsync(c->h_count, c->d_count, sizeof(unsigned int), hipMemcpyDeviceToHost, c->copy_stream));
   c->pending = nframes;
   return HC_OK;
 }
@@ -1155,8 +1172,9 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   for (auto& e : ctx->ev) {
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
+  // (the side stream of the small-batch route is made on first use: every stream alive takes a share of the hardware queues)
   if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
@@ -1201,6 +1219,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+  if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -1287,8 +1306,10 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
     if ((rc = dev_upload(&ctx->d_seg_items[k], seg))) return rc;
   }
   g_alloc_count += 2;
-  HIPCHK(hipHostMalloc((void**)&ctx->h_cand, ctx->cand_cap * sizeof(unsigned long long), hipHostMallocDefault));
-  HIPCHK(hipHostMalloc((void**)&ctx->h_count, sizeof(unsigned int), hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&ctx->h_cand, ctx->cand_cap * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+  HIPCHK(hipHostMalloc((void**)&ctx->h_pub, 2 * sizeof(unsigned int), hipHostMallocCoherent | hipHostMallocMapped));
+  ctx->h_pub[0] = ctx->h_pub[1] = 0;
+  ctx->pub_seq = 0;
   ctx->pending = 0;
   ctx->last_frames = 0;
   ctx->configured = true;
@@ -1385,6 +1406,35 @@ int hc_host_unregister(void* p) {
 }  // extern "C"
 
 namespace {
+// Host wait for an event WITHOUT the runtime's blocking wait: hipEventSynchronize / hipStreamSynchronize on a stream whose
+// hardware queue also carries another context's pending copy return only when THAT copy is done (one batch late).
+int wait_event_polling(hipEvent_t ev) {
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return HC_OK;
+    if (e != hipErrorNotReady) return set_err(HC_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(e));
+    if (spins > 64) std::this_thread::yield();
+  }
+}
+
+// The batch's last kernel has stored sequence number pub_seq (k_publish_flag): poll for it.  Every millisecond or so the
+// batch's completion event is asked for errors, so a faulted kernel ends the wait with an error instead of a hang.
+int wait_published(hc_context* ctx) {
+  const unsigned int want = ctx->pub_seq;
+  int done_polls = 0;
+  for (unsigned int spins = 1;; spins++) {
+    if (__atomic_load_n(&ctx->h_pub[0], __ATOMIC_ACQUIRE) == want) return HC_OK;
+    if (spins < 256) continue;
+    if ((spins & 4095u) == 0) {
+      const hipError_t e = hipEventQuery(ctx->ev_done);
+      if (e != hipSuccess && e != hipErrorNotReady) return set_err(HC_ERR_HIP, std::string("batch failed: ") + hipGetErrorString(e));
+      if (e == hipSuccess && ++done_polls > 1000)
+        return set_err(HC_ERR_HIP, "the batch completed but its result flag was never published");
+    }
+    std::this_thread::yield();
+  }
+}
+
 // waits for the enqueued batch and groups its candidates: grouped[f] = boxes of frame f
 int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   HIPCHK(hipSetDevice(ctx->device));
@@ -1392,8 +1442,8 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   ctx->pending = 0;
   unsigned int count = 0;
   for (int attempt = 0;; attempt++) {
-    HIPCHK(hipStreamSynchronize(ctx->copy_stream));     // this batch's kernels + count copy are done
-    count = *ctx->h_count;
+    if (int rcw = wait_published(ctx)) return rcw;      // this batch's kernels are done, count and candidates are in host memory
+    count = ctx->h_pub[1];
     if (ctx->debug_max_stages > 0 && count > ctx->cand_cap) count = 0;   // timing experiments only
     if (count <= ctx->cand_cap) break;
     // More raw candidates than the workspace holds (the counter keeps counting past the capacity, so the need is
@@ -1412,7 +1462,7 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
     int rc = dev_alloc(&ctx->d_cand, want);
     if (rc) return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing it failed: " + g_err);
     g_alloc_count++;
-    if (hipHostMalloc((void**)&ctx->h_cand, want * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc((void**)&ctx->h_cand, want * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess)
       return set_err(HC_ERR_CAND_OVERFLOW, "raw candidate workspace overflow; growing the host buffer failed");
     ctx->cand_cap = want;
     if (!may_rerun)
@@ -1427,11 +1477,6 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   ctx->last_frames = nframes;
   ctx->last_raw.clear();
   ctx->last_raw_ofs.assign(nframes + 1, 0);
-  if (count) {
-    HIPCHK(hipMemcpyAsync(ctx->h_cand, ctx->d_cand, (size_t)count * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                          ctx->copy_stream));
-    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
-  }
   // canonical single-thread order: frame -> scale -> y -> x  == ascending key
   std::sort(ctx->h_cand, ctx->h_cand + count);
   const hc::Plan& P = ctx->plan;
@@ -1663,7 +1708,8 @@ static int faces_wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& g
                                      ctx->d_boxsums);
     if (e) return set_err(HC_ERR_HIP, std::string("k_box_mask_sums launch: ") + hipGetErrorString((hipError_t)e));
     HIPCHK(hipMemcpyAsync(ctx->h_boxsums, ctx->d_boxsums, (size_t)nb * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
-    HIPCHK(hipStreamSynchronize(ctx->copy_stream));
+    HIPCHK(hipEventRecord(ctx->ev_copied, ctx->copy_stream));
+    if (int rcw = wait_event_polling(ctx->ev_copied)) return rcw;
   }
   int k = 0;
   for (auto& g : grouped) {
@@ -1781,6 +1827,8 @@ int hc_context_read_tap(hc_context* ctx, int frame, int level, int what, void* d
     }
     case HC_TAP_SUM:
     case HC_TAP_SQSUM: {
+      if (what == HC_TAP_SQSUM && !ctx->sq_valid)
+        return set_err(HC_ERR_STATE, "the squares' integral was not materialised: enable stage taps before the enqueue");
       const size_t wbytes = (size_t)(L.w + 1) * 4;
       if (dst_bytes < wbytes * (L.h + 1)) return set_err(HC_ERR_CAPACITY, "tap buffer too small");
       const uint32_t* src = (what == HC_TAP_SUM ? ctx->d_sum : ctx->d_sq) + (size_t)frame * P.int_words + L.int_ofs;

@@ -253,8 +253,8 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
     uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
     size_t pyr_stride, int R, int lds_pitch, int src_pitch, float* __restrict__ vnf, size_t grid_stride, int norm_w,
-    int norm_h) {
-  extern __shared__ uint32_t rowbuf[];   // [2][R][lds_pitch] row prefixes | [lds_pitch] x table | per wave 2 source rows
+    int norm_h, int xr_pitch, int store_sq) {
+  extern __shared__ uint32_t rowbuf[];   // [2][R][lds_pitch] row prefixes | [lds_pitch] x table | per wave 2 source rows | [NH][xr_pitch] ring words
   uint32_t* rs = rowbuf;
   uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
   uint32_t* xt_s = rowbuf + (size_t)2 * R * lds_pitch;
@@ -270,7 +270,13 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
   const uint8_t* src = frames + (size_t)frame * frame_stride;
   const uint32_t* yt_l = ytab + L.ytab_ofs;
   uint32_t* S = sum + (size_t)frame * int_stride + L.int_ofs;
-  uint32_t* Q = sq ? sq + (size_t)frame * int_stride + L.int_ofs : nullptr;   // null: sum only (mask integral)
+  const bool squares = sq != nullptr;                                          // false: sum only (mask integral)
+  // the squares' integral is stored when somebody reads it: a debug tap, a k_variance launch of a shared pass, or this
+  // kernel's own read-back route for grid columns that no ring covers.  With the rings it stays in LDS (a third of the
+  // kernel's HBM writes on the bench route).
+  const bool xring_on = NH > 0 && xr_pitch > 0;
+  uint32_t* Q = squares && (store_sq || (NH > 0 && !xring_on && L.nx > VR_COLS * PI_THREADS) || NH == 0)
+                    ? sq + (size_t)frame * int_stride + L.int_ofs : nullptr;
   uint8_t* P = pyr ? pyr + (size_t)frame * pyr_stride + L.pyr_ofs : nullptr;
   const bool dwords = ((((size_t)src) | row_step) & 3) == 0;               // uniform: rows are 4-byte aligned
   uint32_t col_s[CMAX], col_q[CMAX];
@@ -285,7 +291,10 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
       for (int i = 0; i < VR_RING; i++) V.pk[k][i] = 0;
     }
   }
-  int ph = 0;
+  uint32_t* const xring = xring_on ? (uint32_t*)((uint8_t*)(xt_s + lds_pitch) + (size_t)(PI_THREADS / 64) * 2 * src_pitch) : nullptr;
+  if (xring_on)
+    for (int i = threadIdx.x; i < ((NH > 0 ? NH : 1) + 2) * xr_pitch; i += PI_THREADS) xring[i] = 0u;   // NH ring slots + the two running sums
+  int ph = 0, xslot = 0;
   for (int x = threadIdx.x; x < lds_pitch; x += PI_THREADS) xt_s[x] = x < w ? xtab[L.xtab_ofs + x] : 0u;
   __syncthreads();
   // The two source rows of a wavefront's NEXT destination row are requested at the end of its phase 1 and wait in
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
           for (; r + 4 <= nr; r += 4) {                     // four rows' prefixes requested together
             uint32_t a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { a[u] = rs[(r + u) * lds_pitch + x]; b[u] = rq[(r + u) * lds_pitch + x]; }
+            for (int u = 0; u < 4; u++) { a[u] = rs[(r + u) * lds_pitch + x]; b[u] = qo ? rq[(r + u) * lds_pitch + x] : 0u; }   // squares only when stored
 #pragma unroll
             for (int u = 0; u < 4; u++) {
               cs += a[u]; cq += b[u];
@@ -426,9 +435,11 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
           }
           for (; r < nr; r++) {
             cs += rs[r * lds_pitch + x];
-            cq += rq[r * lds_pitch + x];
             st_u32_at(so + (size_t)r * pitch, x * 4u, cs);
-            if (qo) st_u32_at(qo + (size_t)r * pitch, x * 4u, cq);
+            if (qo) {
+              cq += rq[r * lds_pitch + x];
+              st_u32_at(qo + (size_t)r * pitch, x * 4u, cq);
+            }
           }
           col_s[k] = cs; col_q[k] = cq;
         }
@@ -442,8 +453,35 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
         if (ph == 0) variance_rows<NH ? NH : 1, 0, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
         else if (ph == 1) variance_rows<NH ? NH : 1, 1, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
         else variance_rows<NH ? NH : 1, 2, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        // Grid columns beyond VR_COLS * PI_THREADS (two levels of a 720p ladder: 66 and 12 columns): the same slide with
+        // the ring words in LDS, exactly NH slots per column (slot = row mod NH: the word read is the one replaced).
+        // A plain loop on the first wavefronts only.
+        const int gx = (int)threadIdx.x + VR_COLS * PI_THREADS;
+        if (xring_on && gx < L.nx) {
+          const int ys = L.ystep, gnx = L.nx, gny = L.ny;
+          uint32_t* const acc = xring + (NH ? NH : 1) * xr_pitch + (int)threadIdx.x;
+          uint32_t xs = acc[0], xq = acc[xr_pitch];
+          int slot = xslot;
+#pragma unroll 1
+          for (int r = 0; r < nr; r++) {
+            const int xo = r * lds_pitch + gx * ys;
+            const uint32_t bs = rs[xo + norm_w] - rs[xo], bq = rq[xo + norm_w] - rq[xo];
+            uint32_t* const sp = xring + slot * xr_pitch + (int)threadIdx.x;
+            const uint32_t old = *sp;
+            const uint32_t obs = old & 0x1fffu, obq = 255u * obs - (old >> 13);
+            xs += bs - obs;
+            xq += bq - obq;
+            *sp = bs | ((255u * bs - bq) << 13);
+            const int yt = y0 + r - (NH ? NH : 1);
+            const int gy = ys == 1 ? yt : (yt >> 1);
+            if (yt >= 0 && (ys == 1 || !(yt & 1)) && gy < gny) vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)xs, xq, area);
+            slot = slot + 1 == (NH ? NH : 1) ? 0 : slot + 1;
+          }
+          acc[0] = xs; acc[xr_pitch] = xq;
+        }
       }
       ph = ph == 2 ? 0 : ph + 1;
+      xslot = (xslot + nr) % (NH ? NH : 1);
     }
     __syncthreads();
     // Phase 3 (A.6a fused in): the variance factor of every window whose inner rect ENDS in this chunk.  Its 8 integral
@@ -451,7 +489,7 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
     // the barrier above (s_waitcnt vmcnt(0) precedes it) and never read by this CU before their final value was
     // written, so they come back from L2 (or L1) current; no other kernel has to re-read the integrals for this.
     // Uses no LDS: the wavefronts that finish first go on to the next chunk's phase 1.
-    if (vnf && Q && L.nx > (NH > 0 ? VR_COLS * PI_THREADS : 0)) {   // NH > 0: only the grid columns beyond the ring's
+    if (vnf && Q && !xring_on && L.nx > (NH > 0 ? VR_COLS * PI_THREADS : 0)) {   // NH > 0: only the grid columns beyond the ring's
       const int ys = L.ystep, gnx = L.nx, gny = L.ny;
       // window row y = gy*ys has its bottom integral row at y + 1 + norm_h; rows y0+1 .. y0+nr were finished just now
       int gy_lo = max(y0 - norm_h, 0);
@@ -610,12 +648,42 @@ int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames
   return 0;
 }
 
+// ---- results to the host without a copy command --------------------------------------------------
+// The last two launches of a batch: the raw candidates go to page-locked host memory by plain stores (a few thousand
+// 8-byte words per batch), then one thread publishes {count, sequence number}.  The host polls the sequence word
+// (hc_api.cpp wait_core): a completion that does not pass through the runtime's stream / event waits, which return only
+// when the hardware queue they share with another context's streams has drained (one whole batch late with four
+// contexts alive).  h_cand / h_pub are coherent host allocations (hipHostMallocCoherent): device stores bypass the caches.
+__global__ __launch_bounds__(256) void k_publish_candidates(const unsigned int* __restrict__ count, const unsigned long long* __restrict__ cand,
+                                                            unsigned int cap, unsigned long long* __restrict__ h_cand) {
+  const unsigned int n = min(*count, cap);
+  for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) h_cand[i] = cand[i];
+}
+
+__global__ void k_publish_flag(const unsigned int* __restrict__ count, unsigned int* h_pub, unsigned int seq) {
+  h_pub[1] = *count;
+  __threadfence_system();
+  __hip_atomic_store(&h_pub[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int launch_publish(hipStream_t st, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
+                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq) {
+  if (cap && cand && h_cand) {
+    hipLaunchKernelGGL(k_publish_candidates, dim3(32), dim3(256), 0, st, count, cand, cap, h_cand);
+    HC_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, st, count, h_pub, seq);
+  HC_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
-                            uint8_t* pyr, size_t pyr_stride, float* vnf, size_t grid_stride, int norm_w, int norm_h) {
+                            uint8_t* pyr, size_t pyr_stride, float* vnf, size_t grid_stride, int norm_w, int norm_h,
+                            int max_nx, bool store_sq, bool* sq_stored) {
   if (nlevels == 0 || nframes == 0) return 0;
-  const int lds_pitch = (max_w + 63) & ~63;
+  int lds_pitch = (max_w + 63) & ~63;
   const int src_pitch = (cols + 3 + 3) & ~3;     // staged source row: dword granular, >= cols
   const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
   int R = PI_THREADS / 64;                       // rows per chunk: (2 R + 1) x pitch words + staging rows of LDS
@@ -625,17 +693,42 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
     while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 + stage > 147456u) R >>= 1;
   }
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
-  const size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
+  size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
+  int xr_pitch = 0;
 #define HC_PI(C, NH)                                                                                              \
   hipLaunchKernelGGL((k_pyramid_integral<C, NH>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                      levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
-                     norm_w, norm_h)
+                     norm_w, norm_h, xr_pitch, store_sq ? 1 : 0)
   // variance factors from the row prefixes in LDS (register ring, variance_rows): chunks of 8 rows, at most two grid
   // columns per thread, the stock inner-rect heights, box sums that fit the packed ring word.  Anything else reads the
   // integrals back (NH = 0).  HC_VAR_RING=0 pins the old route (A/B).
   static const bool ring_ok = [] { const char* e = getenv("HC_VAR_RING"); return !e || atoi(e) != 0; }();
   const bool ring = ring_ok && vnf && sq && R == 8 && PI_THREADS == 512 && norm_w <= 32 &&
                     (norm_h == 18 || norm_h == 22);
+  bool stored = sq != nullptr;
+  if (ring) {
+    // The grid columns beyond the register rings (max_nx - 512 of them) get ring words in LDS, norm_h slots each, when
+    // that still leaves room for two workgroups per CU -- if need be with the row pitch rounded to 4 instead of 64
+    // words.  Then nothing reads the squares' integral and it is not stored (store_sq: a debug tap or another kernel
+    // wants it); otherwise those columns keep the read-back route and their levels store it.
+    static const bool xring_ok = [] { const char* e = getenv("HC_VAR_XRING"); return !e || atoi(e) != 0; }();
+    const int extra = max_nx - VR_COLS * PI_THREADS;
+    stored = store_sq;                     // without the LDS rings only the levels with read-back columns store it
+    if (extra <= 0) {}
+    else if (xring_ok && extra <= PI_THREADS) {
+      const int xp = (extra + 3) & ~3;
+      const size_t ring_bytes = (size_t)(norm_h + 2) * xp * 4;       // + the two running sums per column
+      const int pitch4 = (max_w + 3) & ~3;
+      if (lds + ring_bytes <= 81920u) { xr_pitch = xp; lds += ring_bytes; stored = store_sq; }
+      else if ((size_t)(2 * R + 1) * pitch4 * 4 + stage + ring_bytes <= 81920u) {
+        lds_pitch = pitch4;
+        lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage + ring_bytes;
+        xr_pitch = xp;
+        stored = store_sq;
+      }
+    }
+  }
+  if (sq_stored) *sq_stored = stored;
   if (max_w <= 2 * PI_THREADS) {
     if (ring && norm_h == 18) HC_PI(2, 18);
     else if (ring) HC_PI(2, 22);
