@@ -151,6 +151,13 @@ HC_API int  hc_host_unregister(void* p);
 /* stream: a hipStream_t to enqueue on, or NULL for a stream owned by the context. */
 HC_API int  hc_context_create(const hc_cascade* c, int device, void* stream, hc_context** out);
 HC_API void hc_context_destroy(hc_context* ctx);
+/* The hipStream_t the context enqueues on (its own, or the one it was created with).  A software pipeline of two or
+ * more contexts is fastest with ALL of them on one stream -- hc_context_create(c, dev, hc_context_stream(first), &next):
+ * kernels of consecutive batches then run back to back instead of side by side (two cascade launches sharing the CUs
+ * cost 9 % at 720p), a large host batch (>= 4 MiB) still travels on an upload stream of the context's own while the
+ * previous batch computes, and results come back through host memory, ordered after their own batch only.  The stream
+ * of a context must outlive every context created on it. */
+HC_API void* hc_context_stream(const hc_context* ctx);
 /* Which generation of the call the context evaluates; call before hc_context_configure (it drops the workspace).
  * 0 (default): OpenCV >= 4, everything in this section as described.
  * 1: OpenCV 2.4.x (Appendix B; see hc_detect_multiscale_cv24 above) as a batched, device-resident path: its own scale

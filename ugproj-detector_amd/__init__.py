@@ -71,6 +71,7 @@ lib = C.CDLL(LIB_PATH)
 _SIGS = {
     "hc_cascade_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "hc_cascade_free": (None, [C.c_void_p]),
+    "hc_context_stream": (C.c_void_p, [C.c_void_p]),
     "hc_cascade_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
     "hc_cascade_counts": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_int)] * 3),
     "hc_cascade_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
@@ -276,6 +277,10 @@ class Context:
         self._h = C.c_void_p()
         _check(lib.hc_context_create(cascade._h, device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.max_batch = 0
+
+    def stream(self):
+        """the hipStream_t (as an int) this context enqueues on: pass it to Context(.., stream=) of the next pipeline slot"""
+        return lib.hc_context_stream(self._h)
 
     def close(self):
         if self._h:

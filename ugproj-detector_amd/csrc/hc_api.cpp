@@ -166,6 +166,11 @@ struct hc_context {
   unsigned int* h_pub = nullptr;
   unsigned int pub_seq = 0;
   hipStream_t side_stream = nullptr;   // small batches: the ystep-2 cascade launch runs beside the ystep-1 launch
+  // Large host batches go up on a stream of their own (made on first use) and `stream` waits for ev_uploaded: contexts
+  // that share one stream (kernels of consecutive batches back to back, the fastest arrangement) still get batch i+1's
+  // frames across PCIe while batch i computes.
+  hipStream_t upload_stream = nullptr;
+  hipEvent_t ev_uploaded = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int side_max_batch = 8;              // ... up to this many frames (a full batch fills the chip with one launch)
 
@@ -1218,6 +1223,8 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+  if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
+  if (ctx->ev_uploaded) (void)hipEventDestroy(ctx->ev_uploaded);
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
@@ -1370,15 +1377,31 @@ int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_
   if (ctx->leader) return enqueue_device(ctx, h_frames, frame_stride_bytes, row_step_bytes, nframes);   // frames went up with the leader
   if (int rc = ensure_frames(ctx)) return rc;
   const size_t rows = ctx->plan.rows, cols = ctx->plan.cols;
+  // d_frames is free: the context's previous batch has been waited for (checked above), so the copy may start at once
+  hipStream_t up = ctx->stream;
+  const bool separate = (size_t)nframes * rows * cols >= ((size_t)4 << 20);
+  if (separate) {
+    if (!ctx->upload_stream) {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ctx->ev_uploaded, hipEventDisableTiming));
+    }
+    up = ctx->upload_stream;
+  }
   if (row_step_bytes == cols && (nframes == 1 || frame_stride_bytes == rows * cols)) {
-    HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, (size_t)nframes * rows * cols, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_frames, h_frames, (size_t)nframes * rows * cols, hipMemcpyHostToDevice, up));
   } else {
     for (int f = 0; f < nframes; f++)
       HIPCHK(hipMemcpy2DAsync(ctx->d_frames + (size_t)f * rows * cols, cols, h_frames + (size_t)f * frame_stride_bytes,
-                              row_step_bytes, cols, rows, hipMemcpyHostToDevice, ctx->stream));
+                              row_step_bytes, cols, rows, hipMemcpyHostToDevice, up));
+  }
+  if (separate) {
+    HIPCHK(hipEventRecord(ctx->ev_uploaded, up));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_uploaded, 0));
   }
   return enqueue_device(ctx, ctx->d_frames, rows * cols, cols, nframes);
 }
+
+void* hc_context_stream(const hc_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int hc_host_alloc(size_t bytes, void** out) {
   if (!out || bytes == 0) return set_err(HC_ERR_ARG, "hc_host_alloc: bad arguments");

@@ -131,7 +131,8 @@ int main(int argc, char** argv) {
     HIP(hipMalloc((void**)&D.d_recv, (size_t)N * B * RECORD_INTS * 4));
     HIP(hipHostMalloc((void**)&D.h_send, (size_t)B * RECORD_INTS * 4, hipHostMallocDefault));
     for (auto& c : D.ctx) {
-      HC(hc_context_create(casc, d, nullptr, &c));
+      // the pipeline slots of a GPU share the first one's stream: consecutive batches back to back (include/hip_cascade.h)
+      HC(hc_context_create(casc, d, D.ctx[0] ? hc_context_stream(D.ctx[0]) : nullptr, &c));
       // the reference's call: scaleFactor 1.1, minNeighbors 2, minSize 30x30 (src/tracker/detector.cc:25-31)
       HC(hc_context_configure(c, rows, cols, 1.1, min_neighbors, 30, 30, 0, 0, B, 0));
     }
@@ -251,7 +252,7 @@ int main(int argc, char** argv) {
   }
   for (int d = 0; d < N; d++) {
     HIP(hipSetDevice(d));
-    for (auto& c : dev[d].ctx) hc_context_destroy(c);
+    for (size_t k = sizeof(dev[d].ctx) / sizeof(dev[d].ctx[0]); k-- > 0;) hc_context_destroy(dev[d].ctx[k]);   // the stream's owner last
     NCCL(ncclCommDestroy(comms[d]));
   }
   hc_cascade_free(casc);

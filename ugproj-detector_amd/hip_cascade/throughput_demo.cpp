@@ -85,7 +85,9 @@ int main(int argc, char** argv) {
   if (hc_cascade_load(argv[1], &casc) != HC_OK) { fprintf(stderr, "cannot load cascade: %s\n", hc_last_error()); return 1; }
   hc_context* ctx[2] = {nullptr, nullptr};
   for (auto& c : ctx) {
-    CHECK(hc_context_create(casc, 0, nullptr, &c));
+    // both pipeline slots on ONE stream (the first context's): kernels of consecutive batches back to back; the host
+    // frames of the next batch still go up meanwhile, on the context's own upload stream (include/hip_cascade.h)
+    CHECK(hc_context_create(casc, 0, ctx[0] ? hc_context_stream(ctx[0]) : nullptr, &c));
     // the reference's call: scaleFactor 1.1, minNeighbors 2, minSize 30x30 (src/tracker/detector.cc:25-31)
     CHECK(hc_context_configure(c, rows, cols, 1.1, 2, 30, 30, 0, 0, batch, 0));
   }
@@ -116,7 +118,8 @@ int main(int argc, char** argv) {
   }
   printf("best %.1f frames/s PCIe-inclusive (%s host frames, batch %d, %d batches per round), %ld boxes per pass\n", best, pool.c_str(), batch,
          nbatches, first_total / cycles);
-  for (auto& c : ctx) hc_context_destroy(c);
+  hc_context_destroy(ctx[1]);            // the stream's owner goes last
+  hc_context_destroy(ctx[0]);
   if (pool == "pinned") hc_host_free(frames);
   else if (pool == "registered") CHECK(hc_host_unregister(frames));
   hc_cascade_free(casc);
