@@ -120,15 +120,30 @@ def test_shared_prep_four_cascades_2160p(pkg, oracle, synth):
     assert [c.algorithmic_bytes() for c in ctxs] == [303677664, 303677664, 303677664, 440608352]
     with ThreadPoolExecutor(max_workers=4) as ex:
         want = list(ex.map(lambda oc: oc.detect(frame, 1.1, 2, (30, 30), (0, 0)), ocs))
+    for c in ctxs:
+        c.enable_timing(True)
     for c in ctxs:                                            # leader first, then every follower once
         c.enqueue_host(frame[None])
     total = 0
+    var_ms = []
     for c, (grouped, raw), name in zip(ctxs, want, names):
         got = c.wait(1)
         assert np.array_equal(c.raw_candidates(1)[0], raw), name
         assert np.array_equal(got[0], grouped), name
         total += len(grouped)
+        var_ms.append(c.kernel_ms()["k_variance"])
     assert total >= 16
+    # alt2 and alt_tree have the leader's 20 x 20 window: they scan with ITS variance factors (no k_variance of their
+    # own); default (24 x 24) computes its own
+    assert var_ms[0] > 0.02 and var_ms[3] > 0.02 and var_ms[1] < 0.01 and var_ms[2] < 0.01, var_ms
+    # the batch again: the shared factors are rewritten by the leader while the followers' last scans are long done
+    frame2 = synth.planted(2160, 3840, synth.frame_seed(6), nfaces=6, min_size=60, max_size=400)[0]
+    for c in ctxs:
+        c.enqueue_host(frame2[None])
+    for c, oc, name in zip(ctxs, ocs, names):
+        got = c.wait(1)
+        if name in ("alt2", "alt_tree"):
+            assert np.array_equal(got[0], oc.detect(frame2, 1.1, 2, (30, 30), (0, 0))[0]), name
     for c in ctxs:
         c.close()
 

@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/r3y
 rm -rf $O; mkdir -p $O
 cd $R
-bash tools/exp_e2e.sh > $O/e2e.txt 2>&1; cat $O/e2e.txt
+
 timeout -k 10 900 python -m pytest tests/test_gpu_bench_route.py -m gpu -x -q > $O/gputest.log 2>&1; tail -3 $O/gputest.log
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "demo or driver or shim or pool or cpp" > $O/gputest2.log 2>&1; tail -3 $O/gputest2.log
+for c in 5 3; do timeout -k 10 400 python bench.py --config $c --steps 10 --cpu-sample 0 --no-extra > $O/bench_c$c.json 2> $O/bench_c$c.err; python -c "import json; d=json.load(open(\"$O/bench_c$c.json\")); print($c, d[\"value\"], d[\"ms_per_step\"], d[\"roofline\"][\"all_kernels_ms_per_launch\"], d[\"parity\"][\"bit_exact\"])"; done

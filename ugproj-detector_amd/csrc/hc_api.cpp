@@ -198,6 +198,8 @@ struct hc_context {
   unsigned long long prep_seq = 0, seen_seq = 0;
   int prep_frames = 0;
   hipEvent_t ev_prep = nullptr;        // leader: recorded after the prep kernels of a batch
+  hipEvent_t ev_var = nullptr;         // leader: recorded after its k_variance (followers with the leader's window read its factors)
+  bool vnf_shared = false;             // follower whose window and grid equal the leader's: d_vnf IS the leader's, no k_variance of its own
   bool scan_in_flight = false;         // follower: ev_done of its last scan has been recorded and not yet waited by the leader
   int max_batch = 0, cand_per_frame = 0, min_neighbors = 0;
   size_t cand_cap = 0;                   // raw-candidate capacity of d_cand / h_cand for a whole batch (grows on demand)
@@ -305,12 +307,16 @@ struct hc_context {
   void free_workspace() {
     if (leader) {                      // follower: the integrals belong to the leader
       d_sum = d_sq = nullptr;
+      if (vnf_shared) d_vnf = nullptr;
+      vnf_shared = false;
       auto& f = leader->followers;
       f.erase(std::remove(f.begin(), f.end(), this), f.end());
       leader = nullptr;
     }
     for (hc_context* f : followers) {  // leader going away: followers lose their integrals and must be reconfigured
       f->d_sum = f->d_sq = nullptr;
+      if (f->vnf_shared) f->d_vnf = nullptr;
+      f->vnf_shared = false;
       f->leader = nullptr;
       f->configured = false;
     }
@@ -966,6 +972,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     } else if (c->leader) {
       // shared prep: the leader's kernels have produced (or are producing) the integrals of this very batch
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
+      if (c->vnf_shared) HIPCHK(hipStreamWaitEvent(s, c->leader->ev_var, 0));   // the leader's variance factors of this batch
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
     } else if (use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty())) {
       int max_w = 0, max_nx = 0;
@@ -996,10 +1003,11 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     }
     if (!c->followers.empty()) HIPCHK(hipEventRecord(c->ev_prep, s));
     if (timed) HIPCHK(hipEventRecord(c->ev[3], s));
-    if (!fused_variance &&
+    if (!fused_variance && !c->vnf_shared &&
         (e = hc::launch_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq,
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
+    if (!c->followers.empty()) HIPCHK(hipEventRecord(c->ev_var, s));
     if (c->semantics == 1 &&
         (e = hc::launch_cv24_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq, int_stride,
                                       m.win_w - 2, m.win_h - 2, c->cv.inv_area, c->d_vnf64, grid_stride)))
@@ -1183,6 +1191,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_var, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess) {
     hc_context_destroy(ctx);
     return set_err(HC_ERR_HIP, "cannot create the result stream / event");
@@ -1228,6 +1237,7 @@ void hc_context_destroy(hc_context* ctx) {
   if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
   if (ctx->ev_copied) (void)hipEventDestroy(ctx->ev_copied);
   if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+  if (ctx->ev_var) (void)hipEventDestroy(ctx->ev_var);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   ctx->free_workspace();
@@ -1274,6 +1284,17 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
     leader->followers.push_back(ctx);
     ctx->seen_seq = leader->prep_seq;
     ctx->scan_in_flight = false;
+    // Same window and the same grid as the leader's (alt, alt2 and alt_tree are all 20 x 20): the variance factors are the
+    // same numbers, so the leader's k_variance serves this member too (HC_SHARE_VNF=0 gives every member its own).
+    static const bool share_ok = [] { const char* e = getenv("HC_SHARE_VNF"); return !e || atoi(e) != 0; }();
+    const hc::Model &lm = leader->casc->model, &m = ctx->casc->model;
+    bool same = share_ok && !cv24 && leader->semantics == 0 && lm.win_w == m.win_w && lm.win_h == m.win_h &&
+                leader->plan.grid_elems == P.grid_elems && leader->plan.levels.size() == P.levels.size();
+    for (size_t i = 0; same && i < P.levels.size(); i++) {
+      const hc::DevLevel &a = leader->plan.levels[i], &b = P.levels[i];
+      same = a.nx == b.nx && a.ny == b.ny && a.ny_all == b.ny_all && a.ystep == b.ystep && a.grid_ofs == b.grid_ofs;
+    }
+    ctx->vnf_shared = same;
   } else {
     if ((rc = dev_alloc(&ctx->d_sum, B * P.int_words))) return rc;
     if ((rc = dev_alloc(&ctx->d_sq, B * P.int_words))) return rc;
@@ -1288,11 +1309,12 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
         (rc = dev_upload(&ctx->d_cvtab_a0, ctx->cv.tab_a0)) || (rc = dev_upload(&ctx->d_cvtab_a1, ctx->cv.tab_a1)))
       return rc;
   }
-  if ((rc = dev_alloc(&ctx->d_vnf, cv24 ? 1 : B * P.grid_elems))) return rc;
+  if (ctx->vnf_shared) ctx->d_vnf = leader->d_vnf;
+  else if ((rc = dev_alloc(&ctx->d_vnf, cv24 ? 1 : B * P.grid_elems))) return rc;
   ctx->cand_cap = B * ctx->cand_per_frame;
   if ((rc = dev_alloc(&ctx->d_cand, ctx->cand_cap))) return rc;
   if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
-  if (!cv24) HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
+  if (!cv24 && !ctx->vnf_shared) HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
   if ((rc = dev_upload(&ctx->d_levels, P.levels))) return rc;
   if ((rc = dev_upload(&ctx->d_xtab, P.xtab))) return rc;
   if ((rc = dev_upload(&ctx->d_ytab, P.ytab))) return rc;
