@@ -154,9 +154,49 @@ def load_package():
     return mod
 
 
+def cpu_budget():
+    """Host cores this process tree may really use: the cgroup CPU quota (the GPU box grants 16 cores per GPU as a CFS
+    quota while os.cpu_count() still reports every core of the host -- 256), the affinity mask, the core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(parts[0]) // int(parts[1])))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def host_threads(world):
-    """this rank's share of the node's host cores (the GPU box grants 16 per GPU): frame generator, oracle checker"""
-    return max(1, min(16, (os.cpu_count() or 1) // max(world, 1)))
+    """this rank's share of the host cores it may use (quota-aware): frame generator, oracle checker"""
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or max(world, 1)
+    return max(1, min(16, cpu_budget() // local))
+
+
+def tame_thread_pools(world):
+    """Before torch / numpy are imported: their OpenMP / BLAS pools size themselves by os.cpu_count() (256 on the GPU
+    box) and spin after every parallel region; a few small CPU tensor operations per step then burn the whole CFS quota
+    and the kernel throttles every thread of the rank for tens of milliseconds (measured with one rank and RCCL:
+    nr_throttled 16, 30.6 instead of 15.1 ms per step).  Nothing on the timed path needs a CPU math pool."""
+    n = str(max(1, min(4, host_threads(world))))
+    for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ.setdefault(k, n)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 
 def make_frames_parallel(synth, kind, n, rows, cols, first, nthreads):
@@ -172,6 +212,22 @@ def make_frames_parallel(synth, kind, n, rows, cols, first, nthreads):
     return out
 
 
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: RCCL prints a version banner to stdout when a communicator
+    is made, and rank 0's stdout carries exactly one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 class Env:
     """what one rank process sets up once: device, process group, modules"""
     pass
@@ -179,6 +235,7 @@ class Env:
 
 def setup(args):
     import importlib
+    tame_thread_pools(int(os.environ.get("WORLD_SIZE", "1")))
     import torch   # must come before the HIP library: both bind the same libamdhip64.so.7
     import torch.distributed as dist
 
@@ -202,15 +259,19 @@ def setup(args):
     E.dev = torch.device("cuda", E.devno)
     E.use_dist = E.world > 1 or args.force_dist
     E.nthreads = host_threads(E.world)
+    torch.set_num_threads(max(1, min(4, E.nthreads)))
     # the library's own post-processing pool (candidate decode + grouping per frame) gets its share too
     os.environ.setdefault("HC_HOST_THREADS", str(max(1, min(4, E.nthreads))))
     if E.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=E.dev)
-        else:
-            dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+        with stdout_to_stderr():
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=E.dev)
+                dist.barrier()             # the communicator (and its banner) now, not inside a measured region
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
     E.pkg = load_package()
     E.synth = importlib.import_module("ugproj_detector_amd.synth")
     E.shard = importlib.import_module("ugproj_detector_amd.shard")
@@ -298,20 +359,32 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
         """nsteps batches, software-pipelined two deep; the gather of step i finishes while step i+1 computes.
         Returns (boxes of this rank, gathered dict) of the last step."""
         res = None
+        trace = [] if os.environ.get("HC_BENCH_TRACE") else None      # host-side time per pipeline stage, to stderr
         enqueue(slots[0])
         pending_gather = False
         for i in range(nsteps):
+            t = [time.perf_counter()]
             if i + 1 < nsteps:
                 enqueue(slots[(i + 1) & 1])
+            t.append(time.perf_counter())
             boxes = wait_boxes(slots[i & 1])
+            t.append(time.perf_counter())
             if pending_gather:
                 gatherer.finish()
+            t.append(time.perf_counter())
             start_gather(boxes, i)
+            t.append(time.perf_counter())
             pending_gather = True
             if on_done:
                 on_done(slots[i & 1])
             res = boxes
+            if trace is not None:
+                trace.append([1e3 * (b - a) for a, b in zip(t, t[1:])])
         allb = gatherer.finish()
+        if trace:
+            for i, r in enumerate(trace):
+                print("[trace] rank %d step %3d: enqueue %.2f  wait %.2f  gather.finish %.2f  gather.start %.2f ms" % ((rank, i) + tuple(r)),
+                      file=sys.stderr)
         return res, allb
 
     if warmup > 0:
@@ -437,7 +510,7 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             ns = 0      # the oracle's 2.4 restatement is single-frame; the cpu_baseline leg times the >= 4 path only
         if ns > 0:
             # reported at any N: rank 0's host cores, the same frames (the other ranks wait at the closing barrier)
-            cores = min(os.cpu_count() or 1, 16)   # the GPU box grants a 16-core CPU share per GPU
+            cores = min(cpu_budget(), 16)          # the GPU box grants a 16-core CPU share (CFS quota) per GPU
             sample = distinct[np.arange(ns) % ndist]
             ocs = [oracle_lib.OracleCascade(p) for p in cpaths]
             t1 = time.perf_counter()

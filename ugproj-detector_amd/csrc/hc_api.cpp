@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <chrono>
 #include <thread>
 #include <memory>
 #include <string>
@@ -1466,17 +1467,26 @@ int wait_event_polling(hipEvent_t ev) {
 // batch's completion event is asked for errors, so a faulted kernel ends the wait with an error instead of a hang.
 int wait_published(hc_context* ctx) {
   const unsigned int want = ctx->pub_seq;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool napping = false;
+  unsigned int naps = 0;
   int done_polls = 0;
   for (unsigned int spins = 1;; spins++) {
     if (__atomic_load_n(&ctx->h_pub[0], __ATOMIC_ACQUIRE) == want) return HC_OK;
-    if (spins < 256) continue;
-    if ((spins & 4095u) == 0) {
+    if (!napping) {
+      // The first half millisecond is spun through (a single frame is back in 0.2-0.4 ms); a batch that takes longer is
+      // slept for in 50 us naps: a waiting thread must not eat a core of a CPU quota shared with seven other ranks.
+      if (spins & 63u) { __builtin_ia32_pause(); continue; }
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 500.0) continue;
+      napping = true;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((++naps & 63u) == 0) {
       const hipError_t e = hipEventQuery(ctx->ev_done);
       if (e != hipSuccess && e != hipErrorNotReady) return set_err(HC_ERR_HIP, std::string("batch failed: ") + hipGetErrorString(e));
-      if (e == hipSuccess && ++done_polls > 1000)
+      if (e == hipSuccess && ++done_polls > 200)
         return set_err(HC_ERR_HIP, "the batch completed but its result flag was never published");
     }
-    std::this_thread::yield();
   }
 }
 
