@@ -89,7 +89,7 @@ def spawn_ranks(args):
     (fresh interpreters, this parent never initialises HIP and never execs), relay rank 0's JSON
     line, fail if any rank fails or the run exceeds --spawn-timeout."""
     env = dict(os.environ)
-    env.update(WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+    env.update(WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
     for r in range(args.gpus):

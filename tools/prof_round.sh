@@ -4,6 +4,7 @@
 #   bench_c3.json / _c5   python bench.py --config 3 / 5 (BASELINE configs #3, #5)
 #   bench_2ranks.json     python bench.py --gpus 2 --backend gloo --share-gpu (rehearsal of the multi-rank path on one GPU)
 #   bench_cv24.json       python bench.py --semantics cv24 (the OpenCV-2.4 evaluation of the same call, 720p, alt)
+#   bench_rccl1.json      python bench.py --force-dist --backend nccl (the RCCL code path with one rank)
 #   phase.txt             share of wave time per k_cascade phase (HC_PHASE build, if ugproj-detector_amd/libhip_cascade_PH.so exists)
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default command
 #   pmc_*                 separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ+LDS counters), no tracing mixed in
@@ -16,6 +17,8 @@ timeout -k 10 400 python bench.py --config 3 > $O/bench_c3.json 2> $O/bench_c3.e
 timeout -k 10 600 python bench.py --config 5 --steps 10 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?" >> $O/progress.txt
 timeout -k 10 400 python bench.py --gpus 2 --backend gloo --share-gpu --batch 64 --steps 20 --cpu-sample 0 > $O/bench_2ranks.json 2> $O/bench_2ranks.err; echo "2ranks rc=$?" >> $O/progress.txt
 timeout -k 10 300 python bench.py --semantics cv24 --cpu-sample 0 > $O/bench_cv24.json 2> $O/bench_cv24.err; echo "cv24 rc=$?" >> $O/progress.txt
+# the N > 1 code path (process group, RCCL all-gather of box records, gather pipeline) with ONE rank: must match the plain run
+MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 timeout -k 10 300 python bench.py --force-dist --backend nccl --cpu-sample 0 --no-extra > $O/bench_rccl1.json 2> $O/bench_rccl1.err; echo "rccl1 rc=$?" >> $O/progress.txt
 if [ -f $R/ugproj-detector_amd/libhip_cascade_PH.so ]; then
   HC_LIB_PATH=$R/ugproj-detector_amd/libhip_cascade_PH.so timeout -k 10 200 python bench.py --steps 3 --cpu-sample 0 --no-extra 2>&1 >/dev/null | grep "^\[phase" | tail -2 > $O/phase.txt
 fi

@@ -129,6 +129,8 @@ class BoxGatherer:
         self._h_in = self._h_out = self._d_in = self._d_out = None
         self._event = None
         self._pending = None
+        self._seq = 0
+        self._flag_h = self._flag_d = self._flag_np = None
 
     def _buffers(self, n, world):
         import torch
@@ -141,6 +143,12 @@ class BoxGatherer:
             self._d_in = torch.empty((n, RECORD_INTS), dtype=torch.int32, device=self.device)
             self._d_out = torch.empty((n * world, RECORD_INTS), dtype=torch.int32, device=self.device)
             self._event = torch.cuda.Event()
+            # completion flag: a sequence number copied to page-locked host memory behind the records, polled by finish().
+            # Waiting on the event instead returns when the hardware queue the stream was mapped to has drained, which
+            # with the next batch already enqueued can be a whole batch later (ugproj-detector_amd/csrc/hc_api.cpp, ev_copied).
+            self._flag_h = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+            self._flag_d = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._flag_np = self._flag_h.numpy()
 
     def start(self, frame_ids, boxes_per_frame):
         import torch
@@ -158,6 +166,9 @@ class BoxGatherer:
             self._d_in.copy_(self._h_in, non_blocking=True)
             dist.all_gather_into_tensor(self._d_out, self._d_in)
             self._h_out.copy_(self._d_out, non_blocking=True)
+            self._seq += 1
+            self._flag_d.fill_(self._seq)
+            self._flag_h.copy_(self._flag_d, non_blocking=True)
             self._event.record()
         else:
             dist.all_gather_into_tensor(self._h_out, self._h_in)
@@ -171,7 +182,13 @@ class BoxGatherer:
             allrec = self._rec_local
         else:
             if self.device is not None:
-                self._event.synchronize()
+                import time
+                deadline = time.monotonic() + 30.0
+                while int(self._flag_np[0]) != self._seq:
+                    if time.monotonic() > deadline:      # never seen; the event wait then also surfaces a failed collective
+                        self._event.synchronize()
+                        break
+                    time.sleep(5e-5)
             allrec = self._h_out.numpy().copy()
         over = overflow_counts(allrec, world)
         self.last_records = allrec
