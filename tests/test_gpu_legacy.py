@@ -102,11 +102,16 @@ def test_cv24_colour_input_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
     assert not np.array_equal(want24, want4)
 
 
+@pytest.mark.parametrize("route", ["separate", "fused"])
 @pytest.mark.parametrize("name", ["alt", "alt2", "default", "alt_tree"])
-def test_cv24_batched_context(pkg, oracle, synth, name):
+def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     """The 2.4 evaluation as a batched, device-resident path (hc_context_set_semantics): 6 frames of mixed families in one
-    batch -- the LDS-tiled band kernel with 2.4's node arithmetic for the chain cascades, the window-at-a-time kernel for
-    alt_tree's stage tree.  Stage taps of two frames, raw candidates (minNeighbors 0) and grouped boxes of all."""
+    batch -- the LDS-tiled band kernel with 2.4's node arithmetic for the chain cascades, the preorder sweep on the same
+    tiles for alt_tree's stage tree.  Stage taps of two frames, raw candidates (minNeighbors 0) and grouped boxes of all.
+    Both prep routes: the four separate kernels (cvResize pyramid, two-pass integrals, k_cv24_variance) and the fused
+    k_pyramid_integral<.., SEM = 1> that bench.py's batches take by policy (cvResize arithmetic, integrals and f64
+    factors in one march); with taps on, the fused kernel also leaves the pyramid bytes and both integrals to compare."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1" if route == "fused" else "0")
     path = oracle.cascade_path(name)
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     kinds = ["planted", "texture", "noise"]
@@ -118,9 +123,21 @@ def test_cv24_batched_context(pkg, oracle, synth, name):
     assert [(L.w, L.h, L.ystep, L.nx, L.ny) for L in ctx.levels()] == \
         [(l["w"], l["h"], l["ystep"], l["nx"], l["ny"]) for l in oc.plan_cv24(240, 320, 1.1, (30, 30))]
     ctx.enable_stage_taps(True)
+    ctx.enable_timing(True)
     got = ctx.detect_host(frames)
+    ms = ctx.kernel_ms()
+    if route == "fused":
+        assert ms["k_pyramid_integral"] > 0.01 and ms["k_integral_rows"] < 0.01, ms
+    else:
+        assert ms["k_integral_rows"] > 0.005 and ms["k_integral_cols"] > 0.005, ms
     raws = ctx.raw_candidates(6)
     nraw = 0
+    for li in (0, len(ctx.levels()) // 2):                  # pyramid bytes and integrals of one frame, two levels
+        L = ctx.levels()[li]
+        img = oracle.resize_linear_cv24(frames[4], L.h, L.w)
+        assert np.array_equal(ctx.read_tap(4, li, pkg.TAP_PYRAMID), img), (name, route, li)
+        s_, q_ = oracle.integral(img)
+        assert np.array_equal(ctx.read_tap(4, li, pkg.TAP_SUM), s_) and np.array_equal(ctx.read_tap(4, li, pkg.TAP_SQSUM), q_), (name, route, li)
     for f in range(6):
         grouped, raw, otaps = want[f]
         if f in (0, 4):

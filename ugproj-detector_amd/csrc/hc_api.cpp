@@ -957,7 +957,27 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     if (timed) HIPCHK(hipEventRecord(c->ev[0], s));
     // batch size in 720p-frame equivalents decides the small-batch policies (prep kernels, segments, side stream)
     const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
+    bool cv24_fused = false;
     if (c->semantics == 1) {
+      // OpenCV 2.4 through the fused prep kernel (cvResize arithmetic, integrals and the f64 variance factors in one march,
+      // nothing materialised in between) when the geometry fits its ring route and the batch is large enough for one
+      // workgroup per (level, frame); HC_CV24_FUSED=0 pins the four separate kernels.
+      static const bool fused_ok = [] { const char* e_ = getenv("HC_CV24_FUSED"); return !e_ || atoi(e_) != 0; }();
+      int max_w = 0, max_nx = 0;
+      for (const hc::DevLevel& L : P.levels) { max_w = std::max(max_w, L.w); max_nx = std::max(max_nx, L.nx); }
+      cv24_fused = fused_ok && c->cv.fused_tables && (c->cv_chain || c->cv_tree_tiled) && use_fused_prep(c, nframes, true) &&
+                   hc::pyramid_integral_takes_cv24(max_w, max_nx, P.cols, m.win_w - 2, m.win_h - 2);
+      if (cv24_fused) {
+        if ((e = hc::launch_pyramid_integral(s, nframes, (int)P.levels.size(), max_w, d_frames, frame_stride, row_step, P.rows, P.cols,
+                                             c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq, int_stride,
+                                             c->taps_enabled ? c->d_pyr : nullptr, pyr_stride, (float*)c->d_vnf64, grid_stride, m.win_w - 2,
+                                             m.win_h - 2, max_nx, c->taps_enabled, &c->sq_valid, 1)))
+          return set_err(HC_ERR_HIP, std::string("k_pyramid_integral (2.4) launch: ") + hipGetErrorString((hipError_t)e));
+        if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
+        fused_variance = true;
+      }
+    }
+    if (c->semantics == 1 && !cv24_fused) {
       // OpenCV 2.4: cvResize pyramid (materialised), the two-pass integrals, f64 variance factors
       if ((e = hc::launch_cv24_resize(s, nframes, (int)P.levels.size(), c->cv.max_pix, d_frames, frame_stride, row_step, P.rows, P.cols,
                                       c->d_cvlevels, c->d_cvtab_ofs, c->d_cvtab_a0, c->d_cvtab_a1, c->d_pyr, pyr_stride)))
@@ -970,6 +990,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       if ((e = hc::launch_integral_cols(s, nframes, (int)P.col_items.size(), c->d_levels, c->d_col_items, c->d_sum, c->d_sq, int_stride)))
         return set_err(HC_ERR_HIP, std::string("k_integral_cols launch: ") + hipGetErrorString((hipError_t)e));
       fused_variance = true;           // the generic k_variance below is the >= 4 gate; 2.4 has its own factor
+    } else if (c->semantics == 1) {
+      // (done by the fused kernel above)
     } else if (c->leader) {
       // shared prep: the leader's kernels have produced (or are producing) the integrals of this very batch
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
@@ -1009,7 +1031,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
                                  int_stride, m.win_w - 2, m.win_h - 2, c->d_vnf, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_variance launch: ") + hipGetErrorString((hipError_t)e));
     if (!c->followers.empty()) HIPCHK(hipEventRecord(c->ev_var, s));
-    if (c->semantics == 1 &&
+    if (c->semantics == 1 && !cv24_fused &&
         (e = hc::launch_cv24_variance(s, nframes, (int)P.var_items.size(), c->d_levels, c->d_var_items, c->d_sum, c->d_sq, int_stride,
                                       m.win_w - 2, m.win_h - 2, c->cv.inv_area, c->d_vnf64, grid_stride)))
       return set_err(HC_ERR_HIP, std::string("k_cv24_variance launch: ") + hipGetErrorString((hipError_t)e));

@@ -72,6 +72,13 @@ __device__ __forceinline__ float vnf_from_sums(int valsum, uint32_t valsq, doubl
   return out;
 }
 
+// B.5 (OpenCV 2.4): the f64 factor of a window from the same two sums, no gate (cv24_cascade.hip k_cv24_variance, same expression)
+__device__ __forceinline__ double vnf24_from_sums(int valsum, uint32_t valsq, double inv_area) {
+  const double mean = (double)valsum * inv_area;
+  const double v = (double)valsq * inv_area - mean * mean;
+  return v >= 0. ? sqrt(v) : 1.;
+}
+
 // ------------------------------------------------------------------------------------------
 // A.4  pyramid: dst(level, dy, dx) from the ORIGINAL frame, 8.8 x 8.8 fixed point
 // block = 64 x 4 destination pixels
@@ -219,7 +226,7 @@ struct VarRing {
   uint32_t ws[VR_COLS], wq[VR_COLS];
 };
 
-template <int NH, int PH, int R0>   // PH = (y0 / 8) mod 3: the ring slot of the chunk's row r is PH * 8 + r; rows R0 .. 7
+template <int NH, int PH, int R0, int SEM>   // PH = (y0 / 8) mod 3: the ring slot of the chunk's row r is PH * 8 + r; rows R0 .. 7
 __device__ __forceinline__ void variance_rows(VarRing& V, const uint32_t* rs, const uint32_t* rq, int lds_pitch, int nr, int y0,
                                               int ys, int gnx, int gny, int nw, double area, float* __restrict__ vout) {
   static_assert(NH > 0 && NH < VR_RING, "ring must be longer than the inner rect is tall");
@@ -240,14 +247,21 @@ __device__ __forceinline__ void variance_rows(VarRing& V, const uint32_t* rs, co
         V.ws[k] += bs - obs;
         V.wq[k] += bq - obq;
         V.pk[k][slot_w] = bs | ((255u * bs - bq) << 13);
-        if (emit) vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)V.ws[k], V.wq[k], area);
+        if (emit) {
+          if (SEM == 1) ((double*)vout)[(size_t)gy * gnx + gx] = vnf24_from_sums((int)V.ws[k], V.wq[k], area);   // area = 1 / area here
+          else vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)V.ws[k], V.wq[k], area);
+        }
       }
     }
-    variance_rows<NH, PH, R0 + 1>(V, rs, rq, lds_pitch, nr, y0, ys, gnx, gny, nw, area, vout);
+    variance_rows<NH, PH, R0 + 1, SEM>(V, rs, rq, lds_pitch, nr, y0, ys, gnx, gny, nw, area, vout);
   }
 }
 
-template <int CMAX, int NH>   // CMAX columns per thread: level width <= PI_THREADS * CMAX; NH: 0, or norm_h with the variance ring
+// SEM 1: the OpenCV 2.4 generation of the same pass (cvResize's 11-bit coefficients and rounding; f64 variance factors without
+// a gate, 8 bytes per window) -- same march, same integrals, other numbers.  Its tables pack, per destination column / row,
+// source index (13 bits) | first coefficient a0 (12 bits) << 13 | (a0 + a1 - 2047) << 25; the host builds them so that the
+// general formula also reproduces 2.4's copy and exact-half special cases (legacy_cv24.cpp).  Ring route only (NH > 0).
+template <int CMAX, int NH, int SEM = 0>   // CMAX columns per thread: level width <= PI_THREADS * CMAX; NH: 0, or norm_h with the variance ring
 __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integral(
     const uint8_t* __restrict__ frames, size_t frame_stride, size_t row_step, int rows, int cols,
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
   auto prefetch = [&](int dy) {
     if (NPF == 0 || !dwords || dy >= h) return;
     const uint32_t yt = yt_l[dy];
-    const int oy = yt >> 9, oy1 = min(oy + 1, rows - 1);
+    const int oy = SEM == 1 ? (int)(yt & 0x1fffu) : (int)(yt >> 9), oy1 = min(oy + 1, rows - 1);
     const uint32_t* g0 = (const uint32_t*)(src + (size_t)oy * row_step);
     const uint32_t* g1 = (const uint32_t*)(src + (size_t)oy1 * row_step);
     const int nd = (cols + 3) >> 2;
@@ -328,8 +342,10 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
     for (int r = wave; r < nr; r += PI_THREADS / 64) {
       const int dy = y0 + r;
       const uint32_t yt = yt_l[dy];
-      const int oy = yt >> 9, oy1 = min(oy + 1, rows - 1);
-      const uint32_t cy1 = yt & 511u, cy0 = 256u - cy1;
+      const int oy = SEM == 1 ? (int)(yt & 0x1fffu) : (int)(yt >> 9), oy1 = min(oy + 1, rows - 1);
+      // SEM 0: 8.8 weights cy0 + cy1 = 256;  SEM 1: 2.4's 11-bit pair b0, b1 (their sum is 2047 .. 2049)
+      const uint32_t cy1 = SEM == 1 ? ((yt >> 13) & 0xfffu) + 0u : (yt & 511u);
+      const uint32_t cy0 = SEM == 1 ? 2047u + (yt >> 25) - cy1 : 256u - cy1;
       const uint8_t* g0 = src + (size_t)oy * row_step;
       const uint8_t* g1 = src + (size_t)oy1 * row_step;
       if (dwords) {
@@ -381,11 +397,21 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
 #pragma unroll
           for (int u = 0; u < PI_UNROLL; u++) {
             const uint32_t xt = xts[u];
-            const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
-            const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
-            const uint32_t h0 = cx0 * sr0[ox] + cx1 * sr0[ox1];
-            const uint32_t h1 = cx0 * sr1[ox] + cx1 * sr1[ox1];
-            px[u] = x + u < w ? (h0 * cy0 + h1 * cy1 + 32768u) >> 16 : 0u;   // weights sum to 2^16: the value is <= 255
+            if (SEM == 1) {
+              // cvResize(CV_INTER_LINEAR) of 2.4: (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2 with
+              // h = p[sx] * a0 + p[sx + 1] * a1; here cy1 holds b0 and cy0 holds b1 (decoded above in that order)
+              const int ox = xt & 0x1fffu, ox1 = min(ox + 1, cols - 1);
+              const uint32_t a0 = (xt >> 13) & 0xfffu, a1 = 2047u + (xt >> 25) - a0;
+              const uint32_t h0 = sr0[ox] * a0 + sr0[ox1] * a1;
+              const uint32_t h1 = sr1[ox] * a0 + sr1[ox1] * a1;
+              px[u] = x + u < w ? (((cy1 * (h0 >> 4)) >> 16) + ((cy0 * (h1 >> 4)) >> 16) + 2u) >> 2 : 0u;
+            } else {
+              const int ox = xt >> 9, ox1 = min(ox + 1, cols - 1);
+              const uint32_t cx1 = xt & 511u, cx0 = 256u - cx1;
+              const uint32_t h0 = cx0 * sr0[ox] + cx1 * sr0[ox1];
+              const uint32_t h1 = cx0 * sr1[ox] + cx1 * sr1[ox1];
+              px[u] = x + u < w ? (h0 * cy0 + h1 * cy1 + 32768u) >> 16 : 0u;   // weights sum to 2^16: the value is <= 255
+            }
           }
         } else {
 #pragma unroll
@@ -448,11 +474,12 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
     if (NH > 0) {
       // A.6a fused in, from the row prefixes of this chunk (see variance_rows); R == 8 on this route
       if (vnf && L.nx > 0) {
-        float* vout = vnf + (size_t)frame * grid_stride + L.grid_ofs;
-        const double area = (double)(norm_w * norm_h);
-        if (ph == 0) variance_rows<NH ? NH : 1, 0, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
-        else if (ph == 1) variance_rows<NH ? NH : 1, 1, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
-        else variance_rows<NH ? NH : 1, 2, 0>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        // SEM 1: 8-byte factors (the buffer is the context's vnf64), and the helper wants 1 / area
+        float* vout = SEM == 1 ? (float*)((double*)vnf + (size_t)frame * grid_stride + L.grid_ofs) : vnf + (size_t)frame * grid_stride + L.grid_ofs;
+        const double area = SEM == 1 ? 1. / (double)(norm_w * norm_h) : (double)(norm_w * norm_h);
+        if (ph == 0) variance_rows<NH ? NH : 1, 0, 0, SEM>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        else if (ph == 1) variance_rows<NH ? NH : 1, 1, 0, SEM>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
+        else variance_rows<NH ? NH : 1, 2, 0, SEM>(V, rs, rq, lds_pitch, nr, y0, L.ystep, L.nx, L.ny, norm_w, area, vout);
         // Grid columns beyond VR_COLS * PI_THREADS (two levels of a 720p ladder: 66 and 12 columns): the same slide with
         // the ring words in LDS, exactly NH slots per column (slot = row mod NH: the word read is the one replaced).
         // A plain loop on the first wavefronts only.
@@ -474,7 +501,10 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
             *sp = bs | ((255u * bs - bq) << 13);
             const int yt = y0 + r - (NH ? NH : 1);
             const int gy = ys == 1 ? yt : (yt >> 1);
-            if (yt >= 0 && (ys == 1 || !(yt & 1)) && gy < gny) vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)xs, xq, area);
+            if (yt >= 0 && (ys == 1 || !(yt & 1)) && gy < gny) {
+              if (SEM == 1) ((double*)vout)[(size_t)gy * gnx + gx] = vnf24_from_sums((int)xs, xq, area);
+              else vout[(size_t)gy * gnx + gx] = vnf_from_sums((int)xs, xq, area);
+            }
             slot = slot + 1 == (NH ? NH : 1) ? 0 : slot + 1;
           }
           acc[0] = xs; acc[xr_pitch] = xq;
@@ -677,11 +707,30 @@ int launch_publish(hipStream_t st, const unsigned int* count, const unsigned lon
   return 0;
 }
 
+// Whether launch_pyramid_integral can run the OpenCV 2.4 generation for this geometry (ring route, every grid column on a ring,
+// two workgroups per CU): mirrors the decisions below.
+bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, int norm_h) {
+  if (PI_THREADS != 512 || max_w > 2 * PI_THREADS || norm_w > 32 || (norm_h != 18 && norm_h != 22)) return false;
+  const char* e = getenv("HC_VAR_RING");
+  if (e && atoi(e) == 0) return false;
+  const int src_pitch = (cols + 3 + 3) & ~3;
+  const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
+  const int R = PI_THREADS / 64;
+  const int lds_pitch = (max_w + 63) & ~63, pitch4 = (max_w + 3) & ~3;
+  if ((size_t)(2 * R + 1) * lds_pitch * 4 + stage > 81920u) return false;
+  const int extra = max_nx - VR_COLS * PI_THREADS;
+  if (extra <= 0) return true;
+  const char* x = getenv("HC_VAR_XRING");
+  if ((x && atoi(x) == 0) || extra > PI_THREADS) return false;
+  const size_t ring_bytes = (size_t)(norm_h + 2) * ((extra + 3) & ~3) * 4;
+  return (size_t)(2 * R + 1) * lds_pitch * 4 + stage + ring_bytes <= 81920u || (size_t)(2 * R + 1) * pitch4 * 4 + stage + ring_bytes <= 81920u;
+}
+
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
                             uint8_t* pyr, size_t pyr_stride, float* vnf, size_t grid_stride, int norm_w, int norm_h,
-                            int max_nx, bool store_sq, bool* sq_stored) {
+                            int max_nx, bool store_sq, bool* sq_stored, int semantics) {
   if (nlevels == 0 || nframes == 0) return 0;
   int lds_pitch = (max_w + 63) & ~63;
   const int src_pitch = (cols + 3 + 3) & ~3;     // staged source row: dword granular, >= cols
@@ -695,16 +744,24 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
   size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
   int xr_pitch = 0;
-#define HC_PI(C, NH)                                                                                              \
+#define HC_PI(C, NH) do {                                                                                         \
+  if (semantics == 1 && NH > 0)                                                                                   \
+    hipLaunchKernelGGL((k_pyramid_integral<C, NH, (NH > 0 ? 1 : 0)>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
+                       levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
+                       norm_w, norm_h, xr_pitch, store_sq ? 1 : 0);                                                \
+  else                                                                                                            \
   hipLaunchKernelGGL((k_pyramid_integral<C, NH>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                      levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
-                     norm_w, norm_h, xr_pitch, store_sq ? 1 : 0)
+                     norm_w, norm_h, xr_pitch, store_sq ? 1 : 0); } while (0)
   // variance factors from the row prefixes in LDS (register ring, variance_rows): chunks of 8 rows, at most two grid
   // columns per thread, the stock inner-rect heights, box sums that fit the packed ring word.  Anything else reads the
   // integrals back (NH = 0).  HC_VAR_RING=0 pins the old route (A/B).
   static const bool ring_ok = [] { const char* e = getenv("HC_VAR_RING"); return !e || atoi(e) != 0; }();
   const bool ring = ring_ok && vnf && sq && R == 8 && PI_THREADS == 512 && norm_w <= 32 &&
                     (norm_h == 18 || norm_h == 22);
+  // the 2.4 generation exists on the ring route only, with every grid column covered by a ring (the caller asks first:
+  // pyramid_integral_takes_cv24)
+  if (semantics == 1 && !(ring && max_w <= 2 * PI_THREADS)) return (int)hipErrorInvalidValue;
   bool stored = sq != nullptr;
   if (ring) {
     // The grid columns beyond the register rings (max_nx - 512 of them) get ring words in LDS, norm_h slots each, when
@@ -729,6 +786,7 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
     }
   }
   if (sq_stored) *sq_stored = stored;
+  if (semantics == 1 && max_nx > VR_COLS * PI_THREADS && xr_pitch == 0) return (int)hipErrorInvalidValue;   // no read-back route in this generation
   if (max_w <= 2 * PI_THREADS) {
     if (ring && norm_h == 18) HC_PI(2, 18);
     else if (ring) HC_PI(2, 22);

@@ -91,6 +91,24 @@ int build_plan_cv24(const Model& m, int rows, int cols, double sf, int min_w, in
     C.ytab = (int)h.tab_ofs.size();
     linear_table24(rows, L.h, h.tab_ofs, h.tab_a0, h.tab_a1);
     C.pyr_ofs = D.pyr_ofs; C.int_ofs = D.int_ofs; C.grid_ofs = D.grid_ofs;
+    // The same tables packed for the fused prep kernel (kernels.hip k_pyramid_integral, SEM 1): index | a0 << 13 |
+    // (a0 + a1 - 2047) << 25.  2.4's two special cases are the general formula with particular coefficients: a copy is
+    // a0 = 2048, a1 = 0 on both axes ((2048 * (p * 2048 >> 4) >> 16) = 4 p, (4 p + 2) >> 2 = p), the exact half is
+    // a0 = a1 = 1024 at index 2 d ((1024 * ((p + q) * 1024 >> 4)) >> 16 = p + q, the 2 x 2 sum + 2 >> 2).
+    D.xtab_ofs = (int)p.xtab.size();
+    D.ytab_ofs = (int)p.ytab.size();
+    for (int axis = 0; axis < 2; axis++) {
+      const int n = axis == 0 ? L.w : L.h, first = axis == 0 ? C.xtab : C.ytab;
+      std::vector<uint32_t>& out = axis == 0 ? p.xtab : p.ytab;
+      for (int d = 0; d < n; d++) {
+        int idx = h.tab_ofs[first + d], a0 = h.tab_a0[first + d], a1 = h.tab_a1[first + d];
+        if (C.resize_mode == 0) { idx = d; a0 = 2048; a1 = 0; }
+        else if (C.resize_mode == 2) { idx = 2 * d; a0 = 1024; a1 = 1024; }
+        const int delta = a0 + a1 - 2047;
+        if (idx < 0 || idx > 0x1fff || a0 < 0 || a0 > 0xfff || delta < 0 || delta > 3) h.fused_tables = false;
+        out.push_back((uint32_t)idx | ((uint32_t)(a0 & 0xfff) << 13) | ((uint32_t)(delta & 3) << 25));
+      }
+    }
     p.pyr_bytes += align_up64((int64_t)L.w * L.h, 64);
     p.int_words += (int64_t)D.int_pitch * (L.h + 1) + 32;
     p.grid_elems += align_up64((int64_t)L.nx * L.ny, 64);

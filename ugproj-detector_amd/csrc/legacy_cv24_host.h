@@ -26,6 +26,7 @@ struct Cv24Host {
   std::vector<short> tab_a0, tab_a1;
   int max_pix = 0, max_pos = 0;
   double inv_area = 0;
+  bool fused_tables = true;              // every table entry fits the packed form of the fused prep kernel (Plan::xtab / ytab)
 };
 // Plan (DevLevel records, integral / variance / band work lists, workspace sizes) + the 2.4-specific tables
 int build_plan_cv24(const Model& m, int rows, int cols, double sf, int min_w, int min_h, int max_w, int max_h, int band_rows1,
