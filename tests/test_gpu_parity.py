@@ -756,6 +756,32 @@ def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, kno
         assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
 
 
+@pytest.mark.parametrize("forced", ["1", None])
+def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, forced):
+    """Levels wider than 1024 columns (1920x1080: 1192) have no ring route in the fused prep kernel: by policy the variance
+    factors then come from k_variance behind it (faster than the kernel's read-back route: 3.8 against 4.5 ms per 96 frames);
+    HC_FUSE_VARIANCE=1 forces the read-back route, which must give the same factors, taps and boxes."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+    if forced:
+        monkeypatch.setenv("HC_FUSE_VARIANCE", forced)
+    else:
+        monkeypatch.delenv("HC_FUSE_VARIANCE", raising=False)
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.planted(1080, 1920, synth.frame_seed(900 + i), nfaces=5, min_size=50, max_size=300)[0] for i in range(2)])
+    ctx = pkg.Context(casc)
+    ctx.configure(1080, 1920, 1.1, 2, (30, 30), (0, 0), 2, 1 << 15)
+    ctx.enable_stage_taps(True)
+    ctx.enable_timing(True)
+    got = ctx.detect_host(frames)
+    ms = ctx.kernel_ms()
+    assert ms["k_pyramid_integral"] > 0.05
+    assert (ms["k_variance"] < 0.01) == bool(forced), ms
+    for f in range(2):
+        grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[f], f, 1.1, (30, 30))
+        assert np.array_equal(ctx.raw_candidates(2)[f], raw) and np.array_equal(got[f], grouped)
+
+
 @pytest.mark.parametrize("name", ["alt", "default", "alt_tree", "alt2"])
 @pytest.mark.parametrize("spec", ["1", "0"])
 def test_compiled_early_stages_and_generic_kernel_agree(pkg, oracle, synth, monkeypatch, name, spec):

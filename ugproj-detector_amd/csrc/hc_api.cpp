@@ -220,6 +220,7 @@ struct hc_context {
   bool allow_spec = true;        // HC_SPEC=0: never the compiled early stages (csrc/spec), always the generic kernel
   bool pair_form = true;         // HC_PAIR_FORM=0: tree stages always walk their trees per lane (A/B, debugging)
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
+  bool fuse_variance_forced = false;   // HC_FUSE_VARIANCE=1: inside the fused prep kernel whatever route that takes
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
   int row_stages = 2;            // stages 0 and 1 in row form (conflict-free LDS reads while 88 % of the windows are alive)
   int debug_max_stages = 0;   // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
@@ -906,6 +907,18 @@ int shared_enqueue_check(hc_context* c, const void* frames, int nframes) {
 // 795x447, the first level of a 720p frame): fused 0.0088 / equiv (0.0135 with the variance factors fused in), floor
 // 0.4 * A^1.45 (0.6 * ..: one 720p frame 0.39, sixteen 3840x2160 frames 18.6); parallel kernels 0.0233 / equiv, plus
 // 0.005 / equiv for k_variance where the fused kernel would have produced the factors.
+// Variance factors inside the fused prep kernel: a context on its own (a shared pass serves cascades with different windows,
+// which run k_variance each), and only where the kernel has its ring route -- the read-back route of wider levels loses to a
+// separate k_variance launch (HC_FUSE_VARIANCE=1 forces it, =0 never fuses).
+bool wants_fused_variance(const hc_context* c) {
+  if (!c->fuse_variance || !c->followers.empty()) return false;
+  if (c->fuse_variance_forced) return true;
+  int max_w = 0;
+  for (const hc::DevLevel& L : c->plan.levels) max_w = std::max(max_w, L.w);
+  const hc::Model& m = c->casc->model;
+  return hc::pyramid_integral_has_ring(max_w, c->plan.cols, m.win_w - 2, m.win_h - 2);
+}
+
 bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance) {
   if (c->fused_prep >= 0) return c->fused_prep > 0;                         // HC_FUSED_PREP pins the route
   const hc::Plan& P = c->plan;
@@ -940,7 +953,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   for (hc_context* f : c->followers)   // the next prep pass overwrites the integrals: the followers' scans of the last one come first
     if (f->scan_in_flight) { HIPCHK(hipStreamWaitEvent(s, f->ev_done, 0)); f->scan_in_flight = false; }
   {
-    const bool fused0 = use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty());
+    const bool fused0 = use_fused_prep(c, nframes, wants_fused_variance(c));
     int rc0;
     if (!c->leader && !P.levels.empty() && (c->taps_enabled || !fused0 || c->semantics == 1) && (rc0 = ensure_pyr(c))) return rc0;
     if (!P.levels.empty() && c->taps_enabled && (rc0 = ensure_taps(c))) return rc0;
@@ -997,13 +1010,13 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       HIPCHK(hipStreamWaitEvent(s, c->leader->ev_prep, 0));
       if (c->vnf_shared) HIPCHK(hipStreamWaitEvent(s, c->leader->ev_var, 0));   // the leader's variance factors of this batch
       if (timed) { HIPCHK(hipEventRecord(c->ev[1], s)); HIPCHK(hipEventRecord(c->ev[2], s)); }
-    } else if (use_fused_prep(c, nframes, c->fuse_variance && c->followers.empty())) {
+    } else if (use_fused_prep(c, nframes, wants_fused_variance(c))) {
       int max_w = 0, max_nx = 0;
       for (const hc::DevLevel& L : P.levels) { max_w = std::max(max_w, L.w); max_nx = std::max(max_nx, L.nx); }
       // the pyramid bytes only exist as a debug tap in this mode
       // a context on its own gets its variance factors from the same kernel (no k_variance launch, no second pass
       // over the integrals); a shared prep pass serves cascades with different windows, which run k_variance each
-      fused_variance = c->fuse_variance && c->followers.empty();
+      fused_variance = wants_fused_variance(c);
       if ((e = hc::launch_pyramid_integral(s, nframes, (int)P.levels.size(), max_w, d_frames, frame_stride, row_step,
                                            P.rows, P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq,
                                            int_stride, c->taps_enabled ? c->d_pyr : nullptr, pyr_stride,
@@ -1228,7 +1241,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
-  if (const char* e_ = getenv("HC_FUSE_VARIANCE")) ctx->fuse_variance = atoi(e_) != 0;
+  if (const char* e_ = getenv("HC_FUSE_VARIANCE")) { ctx->fuse_variance = atoi(e_) != 0; ctx->fuse_variance_forced = ctx->fuse_variance; }
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_PAIR_FORM")) ctx->pair_form = atoi(e_) != 0;

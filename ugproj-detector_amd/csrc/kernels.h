@@ -73,6 +73,7 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
                             uint8_t* pyr, size_t pyr_stride, float* vnf = nullptr, size_t grid_stride = 0, int norm_w = 0,
                             int norm_h = 0, int max_nx = 0, bool store_sq = true, bool* sq_stored = nullptr, int semantics = 0);
+bool pyramid_integral_has_ring(int max_w, int cols, int norm_w, int norm_h);
 bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, int norm_h);
 // FaceDetector::detectFaces pre-steps (face_kernels.hip): BGR -> mask + equalised, masked gray
 int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t frame_stride, size_t row_step, int rows,

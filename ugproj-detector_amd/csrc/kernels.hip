@@ -57,8 +57,11 @@ __device__ __forceinline__ float vnf_from_sums(int valsum, uint32_t valsq, doubl
   float out = 0.f;
   if (nf > 0.) {
     double y = __builtin_amdgcn_rsq(nf);
+#ifndef HC_VNF_NEWTON
+#define HC_VNF_NEWTON 2
+#endif
 #pragma unroll
-    for (int it = 0; it < 2; it++) {
+    for (int it = 0; it < HC_VNF_NEWTON; it++) {
       const double e = __builtin_fma(-(nf * y), y, 1.0);
       y = __builtin_fma(y * 0.5, e, y);
     }
@@ -705,6 +708,20 @@ int launch_publish(hipStream_t st, const unsigned int* count, const unsigned lon
   hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, st, count, h_pub, seq);
   HC_LAUNCH_CHECK();
   return 0;
+}
+
+// Whether the fused kernel would produce the variance factors from its register rings for this geometry (levels of at most
+// 1024 columns, eight rows per chunk at two workgroups per CU, a stock inner rect).  Where it cannot, its read-back
+// route costs more than a separate k_variance launch (1920x1080, 96 frames: 4.54 ms against 2.5 + 1.27), so the caller
+// then leaves the factors to k_variance.
+bool pyramid_integral_has_ring(int max_w, int cols, int norm_w, int norm_h) {
+  if (PI_THREADS != 512 || max_w > 2 * PI_THREADS || norm_w > 32 || (norm_h != 18 && norm_h != 22)) return false;
+  const char* e = getenv("HC_VAR_RING");
+  if (e && atoi(e) == 0) return false;
+  const int src_pitch = (cols + 3 + 3) & ~3;
+  const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
+  const int lds_pitch = (max_w + 63) & ~63;
+  return (size_t)(2 * (PI_THREADS / 64) + 1) * lds_pitch * 4 + stage <= 81920u;
 }
 
 // Whether launch_pyramid_integral can run the OpenCV 2.4 generation for this geometry (ring route, every grid column on a ring,
