@@ -1222,7 +1222,12 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
     if (hipEventCreate(&e) != hipSuccess) { hc_context_destroy(ctx); return set_err(HC_ERR_HIP, "hipEventCreate failed"); }
   }
   // (the side stream of the small-batch route is made on first use: every stream alive takes a share of the hardware queues)
-  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+  // copy_stream (the skin filter's second round trip: box sums of the grouped rectangles while the next batch already runs)
+  // is a HIGH-priority stream: the runtime keeps those on hardware queues of their own, so its few microseconds of work
+  // neither queue behind the next batch's kernels nor wait for them to drain
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
