@@ -163,6 +163,41 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
         assert np.array_equal(got4[f], oc.detect(frames[f], 1.1, 2, (30, 30))[0]), (name, f)
 
 
+def test_cv24_fused_prep_720p_all_taps(pkg, oracle, synth, monkeypatch):
+    """The fused 2.4 prep at the bench geometry: two 1280x720 frames, every level's stage taps (each depends on that window's
+    f64 variance factor -- two levels have more than 512 grid columns, whose ring words live in LDS), the pyramid bytes and
+    integrals of three levels, raw candidates and boxes."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.make_frames(k, 1, 720, 1280, first=620 + i)[0] for i, k in enumerate(["planted", "texture"])])
+    want = [oc.detect_cv24(fr, 1.1, 2, (30, 30), want_taps=True) for fr in frames]
+    ctx = pkg.Context(casc)
+    ctx.set_semantics(True)
+    ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=2, cand_capacity=1 << 15)
+    assert max(L.nx for L in ctx.levels()) > 512
+    ctx.enable_stage_taps(True)
+    ctx.enable_timing(True)
+    got = ctx.detect_host(frames)
+    ms = ctx.kernel_ms()
+    assert ms["k_pyramid_integral"] > 0.05 and ms["k_integral_rows"] < 0.01 and ms["k_variance"] < 0.01, ms
+    raws = ctx.raw_candidates(2)
+    wide = [li for li, L in enumerate(ctx.levels()) if L.nx > 512]
+    for li in (0, wide[0], len(ctx.levels()) - 1):
+        L = ctx.levels()[li]
+        img = oracle.resize_linear_cv24(frames[1], L.h, L.w)
+        assert np.array_equal(ctx.read_tap(1, li, pkg.TAP_PYRAMID), img), li
+        s_, q_ = oracle.integral(img)
+        assert np.array_equal(ctx.read_tap(1, li, pkg.TAP_SUM), s_) and np.array_equal(ctx.read_tap(1, li, pkg.TAP_SQSUM), q_), li
+    for f in range(2):
+        grouped, raw, otaps = want[f]
+        for li in range(len(ctx.levels())):
+            st = ctx.read_tap(f, li, pkg.TAP_STAGES)
+            assert np.array_equal(st, otaps[li]), "frame %d level %d: %d taps differ" % (f, li, int((st != otaps[li]).sum()))
+        assert np.array_equal(raws[f], raw) and np.array_equal(got[f], grouped), f
+    assert sum(len(w[0]) for w in want) > 0
+
+
 def test_cv24_bench_route_720p(pkg, oracle, synth):
     """bench.py --semantics cv24 as a test: 720p, alt, a batch of 24 through the tiled kernel; rank 0 checks frames against the
     oracle's 2.4 restatement before it times anything."""
