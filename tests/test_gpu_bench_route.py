@@ -135,7 +135,8 @@ def test_shared_prep_four_cascades_2160p(pkg, oracle, synth):
     assert total >= 16
     # alt2 and alt_tree have the leader's 20 x 20 window: they scan with ITS variance factors (no k_variance of their
     # own); default (24 x 24) computes its own
-    assert var_ms[0] > 0.02 and var_ms[3] > 0.02 and var_ms[1] < 0.01 and var_ms[2] < 0.01, var_ms
+    # (an interval without a kernel still measures the event records themselves: ~10 us)
+    assert var_ms[0] > 0.04 and var_ms[3] > 0.04 and var_ms[1] < 0.4 * var_ms[0] and var_ms[2] < 0.4 * var_ms[0], var_ms
     # the batch again: the shared factors are rewritten by the leader while the followers' last scans are long done
     frame2 = synth.planted(2160, 3840, synth.frame_seed(6), nfaces=6, min_size=60, max_size=400)[0]
     for c in ctxs:
@@ -313,7 +314,7 @@ def test_bench_default_line_has_extra_configs(pkg):
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     ex = out["extra"]["configs"]
     assert sorted(ex) == ["3", "5"]
-    for k, nf in (("3", 96), ("5", 32)):
+    for k, nf in (("3", 192), ("5", 64)):
         assert "error" not in ex[k], ex[k]
         assert ex[k]["parity"]["bit_exact"] is True and ex[k]["frames_per_step"] == nf
         assert ex[k]["value"] > 0 and 0 < ex[k]["roofline"]["frac"] < 1

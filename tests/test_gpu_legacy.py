@@ -126,10 +126,11 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     ctx.enable_timing(True)
     got = ctx.detect_host(frames)
     ms = ctx.kernel_ms()
+    # (an interval without a kernel still measures its event records, ~5-10 us: compare with the kernel that did run)
     if route == "fused":
-        assert ms["k_pyramid_integral"] > 0.01 and ms["k_integral_rows"] < 0.01, ms
+        assert ms["k_integral_rows"] + ms["k_integral_cols"] < 0.5 * ms["k_pyramid_integral"], ms
     else:
-        assert ms["k_integral_rows"] > 0.005 and ms["k_integral_cols"] > 0.005, ms
+        assert ms["k_integral_rows"] + ms["k_integral_cols"] > 0.5 * ms["k_pyramid_integral"], ms
     raws = ctx.raw_candidates(6)
     nraw = 0
     for li in (0, len(ctx.levels()) // 2):                  # pyramid bytes and integrals of one frame, two levels
@@ -180,7 +181,8 @@ def test_cv24_fused_prep_720p_all_taps(pkg, oracle, synth, monkeypatch):
     ctx.enable_timing(True)
     got = ctx.detect_host(frames)
     ms = ctx.kernel_ms()
-    assert ms["k_pyramid_integral"] > 0.05 and ms["k_integral_rows"] < 0.01 and ms["k_variance"] < 0.01, ms
+    assert ms["k_pyramid_integral"] > 0.05 and ms["k_integral_rows"] < 0.2 * ms["k_pyramid_integral"] and \
+        ms["k_variance"] < 0.2 * ms["k_pyramid_integral"], ms
     raws = ctx.raw_candidates(2)
     wide = [li for li, L in enumerate(ctx.levels()) if L.nx > 512]
     for li in (0, wide[0], len(ctx.levels()) - 1):

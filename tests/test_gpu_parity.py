@@ -776,7 +776,7 @@ def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, forced):
     got = ctx.detect_host(frames)
     ms = ctx.kernel_ms()
     assert ms["k_pyramid_integral"] > 0.05
-    assert (ms["k_variance"] < 0.01) == bool(forced), ms
+    assert (ms["k_variance"] < 0.018) == bool(forced), ms   # the kernel takes ~0.03 ms on two frames; an empty interval still measures its event records (5-10 us)
     for f in range(2):
         grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[f], f, 1.1, (30, 30))
         assert np.array_equal(ctx.raw_candidates(2)[f], raw) and np.array_equal(got[f], grouped)

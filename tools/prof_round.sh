@@ -15,7 +15,7 @@ cd $R && python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.e
 echo "bench done" > $O/progress.txt
 timeout -k 10 400 python bench.py --config 3 > $O/bench_c3.json 2> $O/bench_c3.err; echo "c3 rc=$?" >> $O/progress.txt
 timeout -k 10 600 python bench.py --config 5 --steps 10 > $O/bench_c5.json 2> $O/bench_c5.err; echo "c5 rc=$?" >> $O/progress.txt
-timeout -k 10 400 python bench.py --gpus 2 --backend gloo --share-gpu --batch 64 --steps 20 --cpu-sample 0 > $O/bench_2ranks.json 2> $O/bench_2ranks.err; echo "2ranks rc=$?" >> $O/progress.txt
+timeout -k 10 400 python bench.py --gpus 2 --backend gloo --share-gpu --batch 256 --steps 20 --cpu-sample 0 > $O/bench_2ranks.json 2> $O/bench_2ranks.err; echo "2ranks rc=$?" >> $O/progress.txt
 timeout -k 10 300 python bench.py --semantics cv24 --cpu-sample 0 > $O/bench_cv24.json 2> $O/bench_cv24.err; echo "cv24 rc=$?" >> $O/progress.txt
 # the N > 1 code path (process group, RCCL all-gather of box records, gather pipeline) with ONE rank: must match the plain run
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 timeout -k 10 300 python bench.py --force-dist --backend nccl --cpu-sample 0 --no-extra > $O/bench_rccl1.json 2> $O/bench_rccl1.err; echo "rccl1 rc=$?" >> $O/progress.txt

@@ -219,6 +219,7 @@ struct hc_context {
   bool bank_order = true;        // HC_BANK_ORDER=0: the sparse finish reads the stumps in the dense path's order
   bool allow_spec = true;        // HC_SPEC=0: never the compiled early stages (csrc/spec), always the generic kernel
   bool pair_form = true;         // HC_PAIR_FORM=0: tree stages always walk their trees per lane (A/B, debugging)
+  int frame_chunk = 128;         // HC_FRAME_CHUNK: k_cascade walks a large batch in chunks of this many frames (0: one sweep over all frames)
   bool fuse_variance = true;     // HC_FUSE_VARIANCE=0: always the separate k_variance kernel (A/B, debugging)
   bool fuse_variance_forced = false;   // HC_FUSE_VARIANCE=1: inside the fused prep kernel whatever route that takes
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a fixed threshold in 720p-frame equivalents instead of the cost model of use_fused_prep()
@@ -1063,7 +1064,15 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
     // the two launches (independent: different levels) then run side by side on two streams.
     const bool side = equiv <= c->side_max_batch && !timed && !P.band_items[0].empty() && !P.band_items[1].empty();
     if (side) {
-      if (!c->side_stream) HIPCHK(hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+      if (!c->side_stream) {
+        // a HIGH-priority stream: the runtime keeps those on hardware queues apart from the normal ones, so the side
+        // launch can never land on the queue of `stream` itself (where "side by side" would be one after the other plus
+        // two event hops: 0.33 instead of 0.28 ms for a 720p frame, depending on how many streams the process had made)
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (const char* e_ = getenv("HC_SIDE_PRIO")) { if (atoi(e_) == 0) hi = lo; }
+        HIPCHK(hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, hi));
+      }
       HIPCHK(hipEventRecord(c->ev_fork, s));
       HIPCHK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
     }
@@ -1083,6 +1092,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
       if (c->debug_max_stages > 0) A.nstages = std::min(A.nstages, c->debug_max_stages);   // timing experiments only (HC_DEBUG_MAX_STAGES)
       A.trees = c->d_trees; A.leaves = c->d_leaves; A.g = p16 ? c->geom_p16 : c->geom[k]; A.tile_words = p16 ? c->tile_words_p16 : c->tile_words[k];
       A.sparse_max = c->sparse_max;
+      A.frame_chunk = c->frame_chunk;
       A.row_stages = c->row_stages;
       A.cand = c->d_cand; A.cand_count = c->d_count;
       A.cand_cap = (unsigned int)c->cand_cap;
@@ -1227,6 +1237,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   // neither queue behind the next batch's kernels nor wait for them to drain
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (const char* e_ = getenv("HC_COPY_PRIO")) { if (atoi(e_) == 0) prio_greatest = prio_least; }
   if (hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_copied, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1246,6 +1257,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   if (const char* e_ = getenv("HC_BAND_WAVES1")) ctx->band_waves[0] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_BAND_WAVES2")) ctx->band_waves[1] = atoi(e_) == 8 ? 8 : 4;
   if (const char* e_ = getenv("HC_FUSED_PREP")) ctx->fused_prep = atoi(e_) != 0 ? 1 : 0;
+  if (const char* e_ = getenv("HC_FRAME_CHUNK")) ctx->frame_chunk = std::max(0, atoi(e_)) & ~7;
   if (const char* e_ = getenv("HC_FUSE_VARIANCE")) { ctx->fuse_variance = atoi(e_) != 0; ctx->fuse_variance_forced = ctx->fuse_variance; }
   if (const char* e_ = getenv("HC_INT_WEIGHTS")) ctx->allow_int_weights = atoi(e_) != 0;
   if (const char* e_ = getenv("HC_SPEC")) ctx->allow_spec = atoi(e_) != 0;

@@ -40,6 +40,8 @@ struct CascadeArgs {
                               //   targets of a stage come later in this order
   int int_weights;            // the node weight words hold int32 (w0 == -1 proven): run the exact-integer build
   int spec;                   // >= 1: id of the compiled early stages matching this cascade (spec_lookup), 0: none
+  int frame_chunk;            // > 0: the grid is walked in chunks of this many frames (a multiple of 8), every band of a chunk
+                              //   before the next chunk, so neighbouring bands of a frame stay close in time whatever the batch
 };
 
 // Compiled early stages of one known cascade (csrc/spec/spec_<tag>.hip): what the generic launcher needs to know.
