@@ -270,7 +270,7 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
     const DevLevel* __restrict__ levels, const uint32_t* __restrict__ xtab, const uint32_t* __restrict__ ytab,
     uint32_t* __restrict__ sum, uint32_t* __restrict__ sq, size_t int_stride, uint8_t* __restrict__ pyr,
     size_t pyr_stride, int R, int lds_pitch, int src_pitch, float* __restrict__ vnf, size_t grid_stride, int norm_w,
-    int norm_h, int xr_pitch, int store_sq) {
+    int norm_h, int xr_pitch, int store_sq, int frame_chunk) {
   extern __shared__ uint32_t rowbuf[];   // [2][R][lds_pitch] row prefixes | [lds_pitch] x table | per wave 2 source rows | [NH][xr_pitch] ring words
   uint32_t* rs = rowbuf;
   uint32_t* rq = rowbuf + (size_t)R * lds_pitch;
@@ -281,8 +281,24 @@ __global__ __launch_bounds__(PI_THREADS, (NH > 0 ? 4 : 1)) void k_pyramid_integr
   // the (much slower) per-lane byte path of the vector memory unit
   uint8_t* sr0 = (uint8_t*)(xt_s + lds_pitch) + (size_t)wave * 2 * src_pitch;
   uint8_t* sr1 = sr0 + src_pitch;
-  const HC_CONST DevLevel& L = as_const(levels)[blockIdx.y];
-  const int frame = blockIdx.x;
+  // frames in chunks (see cascade_body.inc): all levels of a chunk of frames before the next chunk, so that several levels of
+  // one frame are in flight together on its XCD and find each other's source rows in L2
+  int level = blockIdx.y, frame = blockIdx.x;
+  if (frame_chunk > 0 && (int)gridDim.x > frame_chunk) {
+    const int n = gridDim.x, nl = gridDim.y, C = frame_chunk;
+    const int id = blockIdx.y * n + blockIdx.x;
+    const int full = n / C, per = C * nl;
+    if (id < full * per) {
+      const int chunk = id / per, rem = id - chunk * per;
+      level = rem / C;
+      frame = chunk * C + (rem - level * C);
+    } else {
+      const int r = n - full * C, rem = id - full * per;
+      level = rem / r;
+      frame = full * C + (rem - level * r);
+    }
+  }
+  const HC_CONST DevLevel& L = as_const(levels)[level];
   const int w = L.w, h = L.h, pitch = L.int_pitch;
   const uint8_t* src = frames + (size_t)frame * frame_stride;
   const uint32_t* yt_l = ytab + L.ytab_ofs;
@@ -758,6 +774,9 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
     R = PI_THREADS / 64;
     while (R > 1 && (size_t)(2 * R + 1) * lds_pitch * 4 + stage > 147456u) R >>= 1;
   }
+  // 32 frames per chunk: 512 resident workgroups = 16 levels of 32 frames (HC_PI_FRAME_CHUNK; 0 = level-major over the whole batch).
+  // Source-row fetch per 512 frames 7.18 -> 4.14 GB at the same kernel time (16: 3.71 GB, +2.7 % time; profiles/r03_experiments.txt).
+  static const int frame_chunk = [] { const char* e = getenv("HC_PI_FRAME_CHUNK"); return e ? (std::max(0, atoi(e)) & ~7) : 32; }();
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
   size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
   int xr_pitch = 0;
@@ -765,11 +784,11 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   if (semantics == 1 && NH > 0)                                                                                   \
     hipLaunchKernelGGL((k_pyramid_integral<C, NH, (NH > 0 ? 1 : 0)>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                        levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
-                       norm_w, norm_h, xr_pitch, store_sq ? 1 : 0);                                                \
+                       norm_w, norm_h, xr_pitch, store_sq ? 1 : 0, frame_chunk);                                   \
   else                                                                                                            \
   hipLaunchKernelGGL((k_pyramid_integral<C, NH>), grid, block, lds, st, frames, frame_stride, row_step, rows, cols,   \
                      levels, xtab, ytab, sum, sq, int_stride, pyr, pyr_stride, R, lds_pitch, src_pitch, vnf, grid_stride,    \
-                     norm_w, norm_h, xr_pitch, store_sq ? 1 : 0); } while (0)
+                     norm_w, norm_h, xr_pitch, store_sq ? 1 : 0, frame_chunk); } while (0)
   // variance factors from the row prefixes in LDS (register ring, variance_rows): chunks of 8 rows, at most two grid
   // columns per thread, the stock inner-rect heights, box sums that fit the packed ring word.  Anything else reads the
   // integrals back (NH = 0).  HC_VAR_RING=0 pins the old route (A/B).
