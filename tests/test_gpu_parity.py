@@ -756,6 +756,38 @@ def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, kno
         assert np.array_equal(ctx.raw_candidates(1)[0], raw) and np.array_equal(got[0], grouped)
 
 
+@pytest.mark.parametrize("chunks", [("8", "8"), ("16", "0"), ("0", "16")])
+def test_frame_chunks_cover_every_frame_and_band(pkg, oracle, synth, monkeypatch, chunks):
+    """Large batches are walked in chunks of frames (k_cascade: all bands of 128 frames before the next 128; k_pyramid_integral:
+    all levels of 32 frames) -- a remap of the workgroup index.  Small chunks (environment knobs) over a batch of 20 frames, which
+    is two full chunks of 8 and a short one: stage taps of every frame and level, raw candidates and boxes."""
+    monkeypatch.setenv("HC_FRAME_CHUNK", chunks[0])
+    monkeypatch.setenv("HC_PI_FRAME_CHUNK", chunks[1])
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+    monkeypatch.setenv("HC_SEG_MAX_BATCH", "0")               # whole bands: the remap lives in the band kernel
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    kinds = ["planted", "texture", "noise"]
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, 240, 320, first=1200 + i)[0] for i in range(20)])
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=20, cand_capacity=1 << 13)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    raws = ctx.raw_candidates(20)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as ex:             # the oracle call releases the GIL
+        want = list(ex.map(lambda fr: oc.detect(fr, 1.1, 2, (30, 30), (0, 0), want_taps=True), frames))
+    for f in range(20):
+        grouped, raw, otaps = want[f]
+        for li in range(len(ctx.levels())):
+            assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (chunks, f, li)
+        assert np.array_equal(raws[f], raw) and np.array_equal(got[f], grouped), (chunks, f)
+    ctx.enable_stage_taps(False)                              # the instantiation without taps, same remap
+    got2 = ctx.detect_host(frames)
+    for f in range(20):
+        assert np.array_equal(got2[f], want[f][0]), (chunks, f)
+
+
 @pytest.mark.parametrize("forced", ["1", None])
 def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, forced):
     """Levels wider than 1024 columns (1920x1080: 1192) have no ring route in the fused prep kernel: by policy the variance
