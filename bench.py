@@ -42,7 +42,7 @@ CONFIGS = {
             label="BASELINE config #2: 1280x720 gray, haarcascade_frontalface_alt"),
     3: dict(rows=1080, cols=1920, cascades=("alt2", "default"), batch=192, cpu_sample=32, parity_frames=4,
             label="BASELINE config #3: 1920x1080 gray, haarcascade_frontalface_alt2 + _default on the same frames"),
-    5: dict(rows=2160, cols=3840, cascades=("alt", "alt2", "alt_tree", "default"), batch=64, cpu_sample=8, parity_frames=1,
+    5: dict(rows=2160, cols=3840, cascades=("alt", "alt2", "alt_tree", "default"), batch=64, cpu_sample=8, parity_frames=2,
             label="BASELINE config #5: 3840x2160 gray, all four data/ cascades on the same frames"),
 }
 EXTRA_CONFIGS = (3, 5)         # measured after the headline, a few steps each (`extra.configs`)
@@ -76,12 +76,13 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def rendezvous_store(world):
+    """The rendezvous of self-spawned ranks: a TCPStore SERVER in the parent, on a port the OS picks at bind time and this
+    process keeps bound for the whole run -- there is no window between choosing a port and a rank binding it (round 3
+    closed a probe socket and hoped the port stayed free).  torch.distributed's store is CPU code: no HIP call here."""
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    return TCPStore("127.0.0.1", 0, world, is_master=True, timeout=timedelta(seconds=600), wait_for_workers=False)
 
 
 def spawn_ranks(args):
@@ -89,7 +90,9 @@ def spawn_ranks(args):
     (fresh interpreters, this parent never initialises HIP and never execs), relay rank 0's JSON
     line, fail if any rank fails or the run exceeds --spawn-timeout."""
     env = dict(os.environ)
-    env.update(WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+    store = rendezvous_store(args.gpus)          # held until every rank has exited
+    env.update(WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(store.port),
+               HC_BENCH_STORE_PORT=str(store.port),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = []
     for r in range(args.gpus):
@@ -125,6 +128,7 @@ def spawn_ranks(args):
             break
         time.sleep(0.05)
     reader.join(timeout=10)
+    del store
     if failed is not None:
         if timed_out:
             sys.stderr.write("bench.py: ranks still running after %.0f s -- terminated\n" % args.spawn_timeout)
@@ -199,6 +203,28 @@ def tame_thread_pools(world):
     os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 
+def spread_indices(B, n):
+    """n batch positions to check against the oracle, chosen so that EVERY kind of place a frame can have in a launch is
+    covered: first and last frame, both sides of every 128-frame boundary (k_cascade's frame chunks) and of 32-frame
+    boundaries (k_pyramid_integral's), then evenly spaced fill.  Round 3 checked frames 0..15 -- chunk 0 of both remaps."""
+    cand = [0, B - 1]
+    for c in (128, 32):
+        for k in range(1, (B + c - 1) // c):
+            cand += [k * c - 1, k * c]
+    step = max(1, B // max(n, 1))
+    cand += [(i * step + step // 2) % B for i in range(n)]
+    out = []
+    for i in cand:
+        if 0 <= i < B and i not in out:
+            out.append(i)
+    # boundaries of the big chunks first, but keep the fill in when the batch has many boundaries
+    if len(out) > n:
+        head = out[:2] + [i for i in out[2:] if (i % 128) in (0, 127)]
+        rest = [i for i in out if i not in head]
+        out = (head + rest)[:n] if len(head) <= n else head[:n]
+    return sorted(out)
+
+
 def make_frames_parallel(synth, kind, n, rows, cols, first, nthreads):
     """n distinct frames (global ids first .. first+n-1), generated on a thread pool (numpy releases the GIL)."""
     import numpy as np
@@ -265,13 +291,20 @@ def setup(args):
     if E.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # self-spawned ranks meet at the store the parent serves (its port was bound before any rank started);
+        # ranks started by torch.distributed.run use the launcher's own rendezvous (env://)
+        kw = {}
+        if os.environ.get("HC_BENCH_STORE_PORT"):
+            from datetime import timedelta
+            kw["store"] = dist.TCPStore("127.0.0.1", int(os.environ["HC_BENCH_STORE_PORT"]), E.world, is_master=False,
+                                        timeout=timedelta(seconds=600))
         with stdout_to_stderr():
             if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=E.dev)
+                dist.init_process_group("nccl", rank=E.rank, world_size=E.world, device_id=E.dev, **kw)
                 dist.barrier()             # the communicator (and its banner) now, not inside a measured region
                 torch.cuda.synchronize()
             else:
-                dist.init_process_group("gloo", rank=E.rank, world_size=E.world)
+                dist.init_process_group("gloo", rank=E.rank, world_size=E.world, **kw)
     E.pkg = load_package()
     E.synth = importlib.import_module("ugproj_detector_amd.synth")
     E.shard = importlib.import_module("ugproj_detector_amd.shard")
@@ -287,7 +320,7 @@ def setup(args):
     return E
 
 
-def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1, timing=True):
+def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1, timing=True, kind=None, distinct=0):
     """One workload, measured: returns the result dict on rank 0 (None elsewhere)."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
@@ -296,14 +329,15 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
     cfg = CONFIGS[cfgno]
     rows, cols = cfg["rows"], cfg["cols"]
     names = tuple(names) if names else cfg["cascades"]
+    kind = kind or args.kind
     B = batch or cfg["batch"]
     cpaths = [pkg.cascade_path(n) for n in names]
     cascs = [pkg.Cascade(p) for p in cpaths]
 
     # ---- synthetic frames: rank r owns global frames [r*B, (r+1)*B) of every step's global batch; its
     # `ndist` distinct frames are the global synthetic frames r*ndist .. (r+1)*ndist-1 (SplitMix64 per index)
-    ndist = min(args.distinct or B, B)
-    distinct = make_frames_parallel(synth, args.kind, ndist, rows, cols, first=rank * ndist, nthreads=E.nthreads)
+    ndist = min(distinct or args.distinct or B, B)
+    distinct = make_frames_parallel(synth, kind, ndist, rows, cols, first=rank * ndist, nthreads=E.nthreads)
     frames_np = distinct[np.arange(B) % ndist]
     d_frames = torch.from_numpy(frames_np).to(dev)
     torch.cuda.synchronize()
@@ -396,12 +430,15 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
     parity = None
     if rank == 0:
         ocs = [oracle_lib.OracleCascade(p) for p in cpaths]
-        per_rank = min(cfg["parity_frames"] if world == 1 else max(2, 16 // world), ndist)
-        jobs = [(r, f) for r in range(world) for f in range(per_rank)]
+        per_rank = min(cfg["parity_frames"] if world == 1 else max(2, 16 // world), B)
+        # batch positions spread over every frame chunk of both kernels (not the first frames of chunk 0); at N > 1 each
+        # rank is checked at ITS OWN positions of the spread, so the ranks together cover the batch
+        allpos = spread_indices(B, max(per_rank * world, per_rank))
+        jobs = [(r, allpos[(r * per_rank + j) % len(allpos)]) for r in range(world) for j in range(per_rank)]
 
         def check(job):
             r, f = job
-            fr = frames_np[f] if r == 0 else synth.make_frames(args.kind, 1, rows, cols, first=r * ndist + f)[0]
+            fr = frames_np[f] if r == 0 else synth.make_frames(kind, 1, rows, cols, first=r * ndist + f % ndist)[0]
             if cv24:
                 per = [ocs[0].detect_cv24(fr, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0]]
             elif len(jobs) >= E.nthreads or len(ocs) == 1:
@@ -416,7 +453,8 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             res = list(ex.map(check, jobs))
         ok = all(r[0] for r in res) and sorted(gathered) == list(range(world * B))
         parity = {"frames_checked": len(jobs), "ranks_checked": world, "boxes": int(sum(r[1] for r in res)),
-                  "bit_exact": bool(ok), "gathered_frames": len(gathered)}
+                  "bit_exact": bool(ok), "gathered_frames": len(gathered),
+                  "batch_positions": [f for r, f in jobs if r == 0]}
         if not ok and not os.environ.get("HC_DEBUG_MAX_STAGES"):
             raise SystemExit("bench: HIP boxes differ from the oracle -- refusing to report a number")
 
@@ -471,11 +509,15 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8/i32 integrals, f32 features, f64 stage sums", "data": "synthetic",
             "config": {"workload": "%s, scaleFactor 1.1, minNeighbors 2, minSize 30x30, S3 '%s' frames"
-                                   % (cfg["label"] if names == cfg["cascades"] else "%dx%d gray, %s" % (cols, rows, cnames), args.kind),
+                                   % (cfg["label"] if names == cfg["cascades"] else "%dx%d gray, %s" % (cols, rows, cnames), kind),
                        "frames_per_gpu_per_step": B, "distinct_frames_per_gpu": ndist,
                        "levels": [sum(1 for L in c.levels() if L.nx > 0) for c in slots[0]],
                        "shared_prep_levels": len(slots[0][0].levels()) if len(slots[0]) > 1 else None,
-                       "parallelism": par},
+                       "parallelism": par,
+                       # what the library reports it launched for the last timed batch, per cascade of the config
+                       # (hc_context_last_launch): kernel build per scan-step class, prep / variance route, frame chunks
+                       "launch": [dict(cascade=n, **{k: v for k, v in c.last_launch().items() if k != "nframes"})
+                                  for n, c in zip(names, slots[0])]},
             "parity": parity,
             "per_rank_fps": [round(B * steps / s, 1) for s in rank_s],
         }
@@ -492,14 +534,24 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             traffic, traffic_src = None, None
             import glob
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if tf and args.kind == "planted" and cfgno == 2 and names == cfg["cascades"] and not cv24:
+            if tf and kind == "planted" and cfgno == 2 and names == cfg["cascades"] and not cv24:
                 try:
                     tj = json.load(open(tf[-1]))
                     traffic = int(tj["kernels"][dom]["hbm_bytes_per_launch"] * B / tj.get("frames_per_launch", 64))
                     traffic_src = os.path.relpath(tf[-1], ROOT)
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            # LDS / VALU counters of the dominant kernel (SURVEY 8d asks for them next to the roofline fraction): from the
+            # committed PMC passes of this same command, like `traffic` (tools/prof_round.sh -> tools/pmc_summary.py --json)
+            lds = None
+            lf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_lds.json")))
+            if lf and kind == "planted" and cfgno == 2 and names == cfg["cascades"] and not cv24:
+                try:
+                    lj = json.load(open(lf[-1]))
+                    lds = dict(lj[dom], source=os.path.relpath(lf[-1], ROOT))
+                except Exception:
+                    lds = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "lds": lds, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": alg_bytes * B,
@@ -519,13 +571,71 @@ def run_config(E, args, cfgno, steps, warmup, batch=0, names=None, cpu_sample=-1
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": round(ns / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d of the same %dx%d '%s' frames through %s, frame-parallel over %d threads, "
-                                             "%.1f s wall" % (ns, cols, rows, args.kind, cnames, cores, dt)}
+                                             "%.1f s wall" % (ns, cols, rows, kind, cnames, cores, dt)}
     for s in slots:
         for c in s:
             c.close()
     del d_frames
     torch.cuda.empty_cache()
     return out
+
+
+def run_e2e(E, args, batches=12, B=256):
+    """end to end -- page-locked host frames -> H2D (0.92 MB per frame) -> detect -> grouped boxes on the
+    host, config #2, through hc_detect_batch_enqueue_host with two pipeline slots on one stream (batch i+1 goes up on the
+    slot's upload stream while batch i computes).  Never the bench `value`; reported as extra.e2e."""
+    import ctypes as C
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    pkg, synth, oracle_lib = E.pkg, E.synth, E.oracle
+    cfg = CONFIGS[2]
+    rows, cols = cfg["rows"], cfg["cols"]
+    path = pkg.cascade_path("alt")
+    casc = pkg.Cascade(path)
+    frames = make_frames_parallel(synth, "planted", 2 * B, rows, cols, first=0, nthreads=E.nthreads)
+    pools = []
+    for k in range(2):                      # the caller's frame pool: page-locked (hc_host_alloc), as a decoder would keep it
+        ptr = C.c_void_p()
+        pkg._check(pkg.lib.hc_host_alloc(B * rows * cols, C.byref(ptr)))
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(B, rows, cols))
+        a[:] = frames[k * B:(k + 1) * B]
+        pools.append((ptr, a))
+    ctxs = []
+    for k in range(2):
+        c = pkg.Context(casc, device=E.devno, stream=ctxs[0].stream() if ctxs else None)
+        c.configure(rows, cols, CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"], CALL["max_size"], max_batch=B,
+                    cand_capacity=4096)
+        ctxs.append(c)
+
+    def run(n):
+        res = [None, None]
+        ctxs[0].enqueue_host(pools[0][1])
+        for i in range(n):
+            if i + 1 < n:
+                ctxs[(i + 1) & 1].enqueue_host(pools[(i + 1) & 1][1])
+            res[i & 1] = ctxs[i & 1].wait(B)
+        return res
+    run(2)
+    E.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(batches)
+    dt = time.perf_counter() - t0
+    oc = oracle_lib.OracleCascade(path)
+    pos = [(k, f) for k in range(2) for f in spread_indices(B, 4)]
+    with ThreadPoolExecutor(max_workers=E.nthreads) as ex:
+        want = list(ex.map(lambda kf: oc.detect(frames[kf[0] * B + kf[1]], CALL["scale_factor"], CALL["min_neighbors"], CALL["min_size"])[0], pos))
+    ok = all(np.array_equal(res[k][f], w) for (k, f), w in zip(pos, want))
+    for c in ctxs:
+        c.close()
+    for ptr, _ in pools:
+        pkg.lib.hc_host_free(ptr)
+    if not ok:
+        raise SystemExit("bench: e2e boxes differ from the oracle")
+    return {"value": round(batches * B / dt, 1), "unit": "frames/s", "batches": batches, "frames_per_batch": B,
+            "ms_per_batch": round(1e3 * dt / batches, 3),
+            "path": "page-locked host frames -> hc_detect_batch_enqueue_host (H2D on the slot's upload stream) -> kernels -> "
+                    "published candidates -> host grouping; two slots on one stream",
+            "parity": {"frames_checked": len(pos), "bit_exact": bool(ok)}}
 
 
 def rank_main(args):
@@ -552,8 +662,27 @@ def rank_main(args):
                                    "parity": r["parity"], "wall_s": round(time.perf_counter() - t0, 1)}
             except BaseException as e:       # the headline line is still printed; the failure is part of the record
                 extra[str(cno)] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the S1 noise / S2 texture families next to the S3 headline (a few steps each, own oracle check,
+        # 128 distinct frames cycled through the 512 batch slots), and the end-to-end figure from host frames
+        kinds = {}
+        for kd in ("noise", "texture"):
+            t0 = time.perf_counter()
+            try:
+                r = run_config(E, args, 2, args.extra_steps, 1, cpu_sample=0, timing=True, kind=kd, distinct=128)
+                kinds[kd] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                             "frames_per_step": r["config"]["frames_per_gpu_per_step"], "distinct_frames": 128,
+                             "roofline": {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "launch_ms")},
+                             "parity": r["parity"], "wall_s": round(time.perf_counter() - t0, 1)}
+            except BaseException as e:
+                kinds[kd] = {"error": "%s: %s" % (type(e).__name__, e)}
+        t0 = time.perf_counter()
+        try:
+            e2e = run_e2e(E, args)
+            e2e["wall_s"] = round(time.perf_counter() - t0, 1)
+        except BaseException as e:
+            e2e = {"error": "%s: %s" % (type(e).__name__, e)}
         if out is not None:
-            out["extra"] = {"configs": extra}
+            out["extra"] = {"configs": extra, "kinds": kinds, "e2e": e2e}
     if E.rank == 0:
         print(json.dumps(out), flush=True)
     if E.use_dist:

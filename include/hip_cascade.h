@@ -309,6 +309,47 @@ HC_API const char* hc_kernel_name(int i);
  * enqueued batch; 0 when any of them ran the generic kernel (other cascade, HC_SPEC=0, non-default band shape). */
 HC_API int hc_context_compiled_stages(hc_context* ctx, int* nstages);
 
+/* What the LAST enqueue of a context actually launched -- which kernel build, which prep / variance route, and the
+ * frame-chunk values both workgroup remaps ran with.  Tests and bench.py read this back instead of trusting that a tuning
+ * variable reached the launcher (every HC_* variable is parsed once, in hc_context_create, into the context).
+ * No counterpart in the reference: cv::CascadeClassifier has one evaluation path. */
+typedef enum hc_variant {
+  HC_VARIANT_NONE = 0,        /* no launch for this scan-step class (no levels)                              */
+  HC_VARIANT_F32 = 1,         /* generic kernel, f32 rect weights                                            */
+  HC_VARIANT_INT = 2,         /* generic kernel, exact integer rect weights                                  */
+  HC_VARIANT_SPEC = 3,        /* compiled early stages (csrc/spec) + generic later stages, 32-bit tile       */
+  HC_VARIANT_P16 = 4,         /* compiled early stages on the 16-bit tile, two windows per lane in row form  */
+  HC_VARIANT_CV24 = 5,        /* 2.4 semantics on the tiled band kernel (stage chain)                        */
+  HC_VARIANT_CV24_TREE = 6,   /* 2.4 semantics, stage tree swept in preorder on the tiles                    */
+  HC_VARIANT_CV24_WINDOW = 7  /* 2.4 semantics, window-at-a-time kernel                                      */
+} hc_variant;
+typedef enum hc_prep_route {
+  HC_PREP_NONE = 0, HC_PREP_FUSED = 1, HC_PREP_PARALLEL = 2, HC_PREP_SHARED_FOLLOWER = 3,
+  HC_PREP_CV24_FUSED = 4, HC_PREP_CV24_PARALLEL = 5
+} hc_prep_route;
+typedef enum hc_variance_route {
+  HC_VAR_NONE = 0,
+  HC_VAR_KERNEL = 1,          /* separate k_variance launch                                                  */
+  HC_VAR_RING = 2,            /* fused: register rings (and LDS rings for the grid columns beyond them)      */
+  HC_VAR_READBACK = 3,        /* fused: integrals read back from global memory                               */
+  HC_VAR_LEADER = 4,          /* shared pass: the leader's factors (same window, or emitted for this member) */
+  HC_VAR_RING_STRIPS = 5,     /* fused, level cut into column strips, rings per strip                        */
+  HC_VAR_CV24_KERNEL = 6      /* 2.4: separate f64 variance kernel                                           */
+} hc_variance_route;
+typedef struct hc_launch_info {
+  int32_t prep_route, variance_route;
+  int32_t pi_frame_chunk, pi_remapped, pi_tail_frames;       /* k_pyramid_integral: chunk size given, 1 if the remap ran,
+                                                                 frames in the short last chunk                          */
+  int32_t casc_frame_chunk, casc_remapped, casc_tail_frames; /* k_cascade, same meaning                                  */
+  int32_t variant[2];                                        /* hc_variant of the scan-step-1 / scan-step-2 launch       */
+  int32_t compiled_stages[2];
+  int32_t segments;                                          /* 1: bands were walked in segments (small batches)         */
+  int32_t side_stream;                                       /* 1: the two cascade launches ran on two streams           */
+  int32_t sq_stored;                                         /* 1: the squares' integral went to global memory           */
+  int32_t nframes;
+} hc_launch_info;
+HC_API int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out);
+
 /* Device and pinned-host allocations the library has made in this process so far (hipMalloc / hipHostMalloc
  * calls): tests use it to show that a steady state allocates nothing. */
 HC_API long long hc_debug_alloc_count(void);

@@ -38,8 +38,9 @@ def main():
     for _ in range(2):                                            # twice through the same persistent buffers
         g.start(ids, boxes)
         got = g.finish()
+    assert (got is not None) == (rank == 0)                       # only the consumer unpacks; the others just took part
     if rank == 0:
-        got.pop(-1, None)                                         # padding records
+        got = {fid: b for fid, b in got.items() if fid != -1}     # padding records
         shard.save_boxes(out, got)                                # SURVEY 8f-4 file format: every box of every frame
         np.save(out + ".rec.npy", g.last_records)
         with open(out + ".json", "w") as f:

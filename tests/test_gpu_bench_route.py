@@ -88,6 +88,40 @@ def test_bench_route_taps_720p_batch24(pkg, oracle, synth):
         assert np.array_equal(raws3[f], want[f][1]) and np.array_equal(got3[f], want[f][0]), "device input: frame %d" % f
 
 
+def test_bench_shape_160_frames_every_chunk(pkg, oracle, synth):
+    """The code path only big batches take, at the real shape and with the library's own knobs: 160 DISTINCT 1280x720
+    frames in one batch are five k_pyramid_integral chunks of 32 frames and, for k_cascade, one full chunk of 128 plus a
+    short one of 32 -- both workgroup remaps, including the tail branch of the cascade kernel's.  Raw candidates (canonical
+    order) and grouped boxes of ALL 160 frames against the oracle; the launch report proves the remaps ran with those
+    values and which kernel builds evaluated the frames (every frame's boxes are consumed downstream: reference
+    src/tracker/face_tracker.cc:290-304)."""
+    import torch
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 160
+    kinds = ["planted", "planted", "texture", "noise"]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        frames = np.stack(list(ex.map(lambda i: synth.make_frames(kinds[i % 4], 1, 720, 1280, first=3000 + i)[0], range(B))))
+    ctx = pkg.Context(casc)
+    ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)
+    d = torch.from_numpy(frames).cuda()
+    ctx.enqueue_device(d.data_ptr(), B)
+    got = ctx.wait(B)
+    raws = ctx.raw_candidates(B)
+    info = ctx.last_launch()
+    assert info["prep_route"] == "fused" and info["variance_route"] == "ring" and info["nframes"] == B, info
+    assert (info["pi_frame_chunk"], info["pi_remapped"], info["pi_tail_frames"]) == (32, 1, 0), info
+    assert (info["casc_frame_chunk"], info["casc_remapped"], info["casc_tail_frames"]) == (128, 1, 32), info
+    assert info["variant"] == ("p16", "spec") and info["segments"] == 0 and info["sq_stored"] == 0, info
+    want = _oracle_many(oc, frames, False)
+    nboxes = 0
+    for f in range(B):
+        assert np.array_equal(raws[f], want[f][1]), "frame %d raw candidates" % f
+        assert np.array_equal(got[f], want[f][0]), "frame %d boxes" % f
+        nboxes += len(want[f][0])
+    assert nboxes >= B          # the planted half alone carries several faces per frame
+
+
 @pytest.mark.parametrize("name", ["alt2", "default", "alt_tree"])
 def test_full_size_2160p_other_cascades(pkg, oracle, synth, name):
     """BASELINE config #5 (all four cascades at 3840x2160; `alt` is covered in test_gpu_parity.py): raw candidates

@@ -133,6 +133,14 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
         assert ms["k_integral_rows"] + ms["k_integral_cols"] > 0.5 * ms["k_pyramid_integral"], ms
     raws = ctx.raw_candidates(6)
     nraw = 0
+    info = ctx.last_launch()
+    assert info["prep_route"] == ("cv24_fused" if route == "fused" else "cv24_parallel"), info
+    assert info["variant"][0] in (("cv24_tree",) if name == "alt_tree" else ("cv24",)), info
+    # the f32 variance-factor tap of the >= 4 layout does not exist in this mode (f64 factors live in another buffer): the
+    # read must fail cleanly instead of copying from a one-element stub
+    with pytest.raises(pkg.HipCascadeError) as ei:
+        ctx.read_tap(0, 0, pkg.TAP_VNF)
+    assert ei.value.code == -4, ei.value
     for li in (0, len(ctx.levels()) // 2):                  # pyramid bytes and integrals of one frame, two levels
         L = ctx.levels()[li]
         img = oracle.resize_linear_cv24(frames[4], L.h, L.w)

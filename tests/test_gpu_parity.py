@@ -774,6 +774,15 @@ def test_frame_chunks_cover_every_frame_and_band(pkg, oracle, synth, monkeypatch
     ctx.enable_stage_taps(True)
     got = ctx.detect_host(frames)
     raws = ctx.raw_candidates(20)
+    # The remaps must have RUN with these values: every knob is parsed into the context when it is created, and the
+    # launch report carries what the launchers were actually given (round 3 cached HC_PI_FRAME_CHUNK in a function static,
+    # so this test silently ran k_pyramid_integral with the value an earlier test of the process had set).
+    info = ctx.last_launch()
+    ccas, cpi = int(chunks[0]), int(chunks[1])
+    assert info["prep_route"] == "fused" and info["nframes"] == 20, info
+    assert (info["casc_frame_chunk"], info["casc_remapped"], info["casc_tail_frames"]) == (ccas, int(ccas > 0), 20 % ccas if ccas else 0), info
+    assert (info["pi_frame_chunk"], info["pi_remapped"], info["pi_tail_frames"]) == (cpi, int(cpi > 0), 20 % cpi if cpi else 0), info
+    assert info["segments"] == 0 and info["variant"] == ("p16", "spec"), info
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=8) as ex:             # the oracle call releases the GIL
         want = list(ex.map(lambda fr: oc.detect(fr, 1.1, 2, (30, 30), (0, 0), want_taps=True), frames))
@@ -981,6 +990,11 @@ def test_p16_build_and_standard_build_agree(pkg, oracle, synth, monkeypatch):
             ctx.enable_stage_taps(taps)
             got = ctx.detect_host(frames)
             raws = ctx.raw_candidates(20)
+            # which build ran is reported by the library, not assumed: a policy change that silently disabled the 16-bit
+            # tile would otherwise leave this test green twice over the same kernel
+            info = ctx.last_launch()
+            assert info["variant"] == (("p16" if on == "1" else "spec"), "spec") and info["segments"] == 0, (on, taps, info)
+            assert info["compiled_stages"][0] > 0 and info["compiled_stages"][1] > 0, info
             for f in range(20):
                 grouped, raw, otaps = want[f]
                 if taps and f in (0, 7, 14):

@@ -61,6 +61,20 @@ class Level(C.Structure):
                 ("pyr_ofs", C.c_int64), ("int_ofs", C.c_int64), ("grid_ofs", C.c_int64)]
 
 
+class LaunchInfo(C.Structure):
+    """hc_launch_info: what the last enqueue of a context launched"""
+    _fields_ = [("prep_route", C.c_int32), ("variance_route", C.c_int32),
+                ("pi_frame_chunk", C.c_int32), ("pi_remapped", C.c_int32), ("pi_tail_frames", C.c_int32),
+                ("casc_frame_chunk", C.c_int32), ("casc_remapped", C.c_int32), ("casc_tail_frames", C.c_int32),
+                ("variant", C.c_int32 * 2), ("compiled_stages", C.c_int32 * 2), ("segments", C.c_int32),
+                ("side_stream", C.c_int32), ("sq_stored", C.c_int32), ("nframes", C.c_int32)]
+
+
+VARIANT_NAMES = ("none", "f32", "int", "spec", "p16", "cv24", "cv24_tree", "cv24_window")       # hc_variant
+PREP_NAMES = ("none", "fused", "parallel", "shared_follower", "cv24_fused", "cv24_parallel")   # hc_prep_route
+VARIANCE_NAMES = ("none", "kernel", "ring", "readback", "leader", "ring_strips", "cv24_kernel")   # hc_variance_route
+
+
 if not os.path.exists(LIB_PATH):
     raise ImportError("libhip_cascade.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
                       "or `make -C ugproj-detector_amd` -- there is no fallback implementation" % LIB_PATH)
@@ -77,6 +91,7 @@ _SIGS = {
     "hc_cascade_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "hc_spec_plugin_load": (C.c_int, [C.c_char_p]),
     "hc_context_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "hc_context_last_launch": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfo)]),
     "hc_cascade_dump": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -388,6 +403,18 @@ class Context:
         n = C.c_int()
         _check(lib.hc_context_compiled_stages(self._h, C.byref(n)))
         return n.value
+
+    def last_launch(self):
+        """what the last enqueue launched, as a dict (hc_context_last_launch): kernel variant per scan-step class
+        ('variant': (step 1, step 2) names), prep / variance route names, and the frame-chunk values of both remaps"""
+        info = LaunchInfo()
+        _check(lib.hc_context_last_launch(self._h, C.byref(info)))
+        d = {k: getattr(info, k) for k, _ in LaunchInfo._fields_ if k not in ("variant", "compiled_stages")}
+        d["variant"] = tuple(VARIANT_NAMES[v] for v in info.variant)
+        d["compiled_stages"] = tuple(info.compiled_stages)
+        d["prep_route"] = PREP_NAMES[info.prep_route]
+        d["variance_route"] = VARIANCE_NAMES[info.variance_route]
+        return d
 
     def read_tap(self, frame, level_index, what):
         L = self.levels()[level_index]

@@ -1,8 +1,10 @@
 // hc_internal.h -- what the translation units behind the C ABI share (never installed, never part of the ABI).
 #pragma once
 
+#include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hip_cascade.h"
@@ -16,9 +18,11 @@ struct hc_cascade {
   // after the first call of each.  At most sync_cache_size() of them (HC_SYNC_CONTEXTS, default 4); the least
   // recently used one is re-configured for a new combination.
   std::vector<hc_context*> sync_ctxs;
-  // rectangles of the last synchronous call that ended in HC_ERR_CAPACITY (hc_detect_multiscale_reread)
-  std::vector<hc_rect> last_result;
-  bool last_result_valid = false;
+  int sync_cache_size = 4;       // HC_SYNC_CONTEXTS, read when the cascade is loaded
+  // Rectangles of a synchronous call that ended in HC_ERR_CAPACITY (hc_detect_multiscale_reread), kept PER CALLING THREAD:
+  // the mutex is released between the failing call and the re-read, and another thread's call on the same cascade
+  // must not take the first thread's rectangles away.  A thread's next synchronous call drops its own entry.
+  std::map<std::thread::id, std::vector<hc_rect>> pending_results;
 };
 
 namespace hc {

@@ -60,6 +60,17 @@ int spec_register(const SpecUnit* u);
 // layout check between the library and a plug-in built from another checkout of these sources
 constexpr int SPEC_PLUGIN_ABI = 5 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
 
+// k_pyramid_integral: the context's knobs that reach the launcher, and what a launch then did (hc_context_last_launch)
+struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; };
+struct PrepLaunchInfo {
+  int frame_chunk = 0;     // chunk size the kernel was given
+  int remapped = 0;        // 1: grid wider than the chunk, the workgroup remap ran
+  int tail_frames = 0;     // frames in the short last chunk (0: none)
+  int rows_per_chunk = 0;  // R
+  int route = 0;           // hc_variance_route of the fused factors (0: none asked for)
+  bool sq_stored = true;   // the squares' integral was written to global memory
+};
+
 // YCrCb skin bounds of cv::inRange (reference src/tracker/detector.cc:18, cfg.detection.skin_lower/upper)
 struct SkinBounds { int32_t lo[3], hi[3]; };
 
@@ -73,10 +84,11 @@ int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
-                            uint8_t* pyr, size_t pyr_stride, float* vnf = nullptr, size_t grid_stride = 0, int norm_w = 0,
-                            int norm_h = 0, int max_nx = 0, bool store_sq = true, bool* sq_stored = nullptr, int semantics = 0);
-bool pyramid_integral_has_ring(int max_w, int cols, int norm_w, int norm_h);
-bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, int norm_h);
+                            uint8_t* pyr, size_t pyr_stride, const PrepKnobs& knobs, float* vnf = nullptr, size_t grid_stride = 0,
+                            int norm_w = 0, int norm_h = 0, int max_nx = 0, bool store_sq = true, PrepLaunchInfo* info = nullptr,
+                            int semantics = 0);
+bool pyramid_integral_has_ring(const PrepKnobs& knobs, int max_w, int cols, int norm_w, int norm_h);
+bool pyramid_integral_takes_cv24(const PrepKnobs& knobs, int max_w, int max_nx, int cols, int norm_w, int norm_h);
 // FaceDetector::detectFaces pre-steps (face_kernels.hip): BGR -> mask + equalised, masked gray
 int launch_face_prep(hipStream_t st, int nframes, const uint8_t* bgr, size_t frame_stride, size_t row_step, int rows,
                      int cols, const SkinBounds& sb, uint8_t* gray, uint8_t* mask, size_t plane_stride, uint32_t* hist,
@@ -100,7 +112,7 @@ int launch_integral_rows(hipStream_t st, int nframes, int nitems, const uint8_t*
 int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                          uint32_t* sum, uint32_t* sq, size_t int_stride);
 int launch_publish(hipStream_t st, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
-                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq);
+                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq, unsigned int* ticket);
 int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride);
@@ -108,6 +120,6 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
 // lds_bytes = tile + vnf + 2 queues + counters
 // *compiled (nullable): number of leading stages that ran as compiled code (SpecUnit), 0 for the generic kernel
 int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
-                   const CascadeArgs& args, int* compiled = nullptr);
+                   const CascadeArgs& args, int* compiled = nullptr, int* variant = nullptr);
 
 }  // namespace hc

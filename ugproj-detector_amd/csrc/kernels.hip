@@ -698,30 +698,38 @@ int launch_resize(hipStream_t st, int nframes, int nitems, const uint8_t* frames
 }
 
 // ---- results to the host without a copy command --------------------------------------------------
-// The last two launches of a batch: the raw candidates go to page-locked host memory by plain stores (a few thousand
-// 8-byte words per batch), then one thread publishes {count, sequence number}.  The host polls the sequence word
-// (hc_api.cpp wait_core): a completion that does not pass through the runtime's stream / event waits, which return only
-// when the hardware queue they share with another context's streams has drained (one whole batch late with four
-// contexts alive).  h_cand / h_pub are coherent host allocations (hipHostMallocCoherent): device stores bypass the caches.
-__global__ __launch_bounds__(256) void k_publish_candidates(const unsigned int* __restrict__ count, const unsigned long long* __restrict__ cand,
-                                                            unsigned int cap, unsigned long long* __restrict__ h_cand) {
-  const unsigned int n = min(*count, cap);
-  for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) h_cand[i] = cand[i];
-}
-
-__global__ void k_publish_flag(const unsigned int* __restrict__ count, unsigned int* h_pub, unsigned int seq) {
-  h_pub[1] = *count;
-  __threadfence_system();
-  __hip_atomic_store(&h_pub[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+// The last launch of a batch: the raw candidates go to page-locked host memory by plain stores (a few thousand 8-byte
+// words per batch); every thread fences its own stores at system scope, the workgroup takes a ticket, and the workgroup
+// that draws the last ticket publishes {count, sequence number} with a release store -- one kernel, so the order
+// "candidates, then flag" rests on fences and the ticket's atomic alone, not on how the runtime flushes between two
+// kernels of a queue.  The host polls the sequence word (api_wait.cpp wait_published): a completion that does not pass
+// through the runtime's stream / event waits, which return only when the hardware queue they share with another
+// context's streams has drained (one whole batch late with four contexts alive).  h_cand / h_pub are coherent host
+// allocations (hipHostMallocCoherent): device stores bypass the caches.
+__global__ __launch_bounds__(256) void k_publish(const unsigned int* __restrict__ count, const unsigned long long* __restrict__ cand,
+                                                 unsigned int cap, unsigned long long* __restrict__ h_cand, unsigned int* h_pub,
+                                                 unsigned int seq, unsigned int* ticket) {
+  const unsigned int total = *count, n = min(total, cap);
+  if (cand && h_cand)
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) h_cand[i] = cand[i];
+  __threadfence_system();                       // this thread's candidate stores are performed for the host ...
+  __syncthreads();                              // ... and so are those of every thread of the workgroup
+  if (threadIdx.x == 0) {
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {                   // every workgroup has fenced its share
+      *ticket = 0u;                             // ready for the next batch (stream order: the next k_publish starts after this one)
+      h_pub[1] = total;
+      __threadfence_system();
+      __hip_atomic_store(&h_pub[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 int launch_publish(hipStream_t st, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
-                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq) {
-  if (cap && cand && h_cand) {
-    hipLaunchKernelGGL(k_publish_candidates, dim3(32), dim3(256), 0, st, count, cand, cap, h_cand);
-    HC_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, st, count, h_pub, seq);
+                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq, unsigned int* ticket) {
+  const bool copy = cap && cand && h_cand;
+  hipLaunchKernelGGL(k_publish, dim3(copy ? 32 : 1), dim3(256), 0, st, count, copy ? cand : nullptr, cap, copy ? h_cand : nullptr, h_pub,
+                     seq, ticket);
   HC_LAUNCH_CHECK();
   return 0;
 }
@@ -730,10 +738,9 @@ int launch_publish(hipStream_t st, const unsigned int* count, const unsigned lon
 // 1024 columns, eight rows per chunk at two workgroups per CU, a stock inner rect).  Where it cannot, its read-back
 // route costs more than a separate k_variance launch (1920x1080, 96 frames: 4.54 ms against 2.5 + 1.27), so the caller
 // then leaves the factors to k_variance.
-bool pyramid_integral_has_ring(int max_w, int cols, int norm_w, int norm_h) {
+bool pyramid_integral_has_ring(const PrepKnobs& knobs, int max_w, int cols, int norm_w, int norm_h) {
   if (PI_THREADS != 512 || max_w > 2 * PI_THREADS || norm_w > 32 || (norm_h != 18 && norm_h != 22)) return false;
-  const char* e = getenv("HC_VAR_RING");
-  if (e && atoi(e) == 0) return false;
+  if (!knobs.var_ring) return false;
   const int src_pitch = (cols + 3 + 3) & ~3;
   const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
   const int lds_pitch = (max_w + 63) & ~63;
@@ -742,10 +749,9 @@ bool pyramid_integral_has_ring(int max_w, int cols, int norm_w, int norm_h) {
 
 // Whether launch_pyramid_integral can run the OpenCV 2.4 generation for this geometry (ring route, every grid column on a ring,
 // two workgroups per CU): mirrors the decisions below.
-bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, int norm_h) {
+bool pyramid_integral_takes_cv24(const PrepKnobs& knobs, int max_w, int max_nx, int cols, int norm_w, int norm_h) {
   if (PI_THREADS != 512 || max_w > 2 * PI_THREADS || norm_w > 32 || (norm_h != 18 && norm_h != 22)) return false;
-  const char* e = getenv("HC_VAR_RING");
-  if (e && atoi(e) == 0) return false;
+  if (!knobs.var_ring) return false;
   const int src_pitch = (cols + 3 + 3) & ~3;
   const size_t stage = (size_t)(PI_THREADS / 64) * 2 * src_pitch;
   const int R = PI_THREADS / 64;
@@ -753,8 +759,7 @@ bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, in
   if ((size_t)(2 * R + 1) * lds_pitch * 4 + stage > 81920u) return false;
   const int extra = max_nx - VR_COLS * PI_THREADS;
   if (extra <= 0) return true;
-  const char* x = getenv("HC_VAR_XRING");
-  if ((x && atoi(x) == 0) || extra > PI_THREADS) return false;
+  if (!knobs.var_xring || extra > PI_THREADS) return false;
   const size_t ring_bytes = (size_t)(norm_h + 2) * ((extra + 3) & ~3) * 4;
   return (size_t)(2 * R + 1) * lds_pitch * 4 + stage + ring_bytes <= 81920u || (size_t)(2 * R + 1) * pitch4 * 4 + stage + ring_bytes <= 81920u;
 }
@@ -762,8 +767,8 @@ bool pyramid_integral_takes_cv24(int max_w, int max_nx, int cols, int norm_w, in
 int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w, const uint8_t* frames,
                             size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels,
                             const uint32_t* xtab, const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride,
-                            uint8_t* pyr, size_t pyr_stride, float* vnf, size_t grid_stride, int norm_w, int norm_h,
-                            int max_nx, bool store_sq, bool* sq_stored, int semantics) {
+                            uint8_t* pyr, size_t pyr_stride, const PrepKnobs& knobs, float* vnf, size_t grid_stride, int norm_w,
+                            int norm_h, int max_nx, bool store_sq, PrepLaunchInfo* info, int semantics) {
   if (nlevels == 0 || nframes == 0) return 0;
   int lds_pitch = (max_w + 63) & ~63;
   const int src_pitch = (cols + 3 + 3) & ~3;     // staged source row: dword granular, >= cols
@@ -776,7 +781,7 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   }
   // 32 frames per chunk: 512 resident workgroups = 16 levels of 32 frames (HC_PI_FRAME_CHUNK; 0 = level-major over the whole batch).
   // Source-row fetch per 512 frames 7.18 -> 4.14 GB at the same kernel time (16: 3.71 GB, +2.7 % time; profiles/r03_experiments.txt).
-  static const int frame_chunk = [] { const char* e = getenv("HC_PI_FRAME_CHUNK"); return e ? (std::max(0, atoi(e)) & ~7) : 32; }();
+  const int frame_chunk = knobs.frame_chunk;      // per context (hc::Knobs), never a process-wide static
   const dim3 grid(nframes, nlevels), block(PI_THREADS);
   size_t lds = (size_t)(2 * R + 1) * lds_pitch * 4 + stage;
   int xr_pitch = 0;
@@ -792,7 +797,7 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
   // variance factors from the row prefixes in LDS (register ring, variance_rows): chunks of 8 rows, at most two grid
   // columns per thread, the stock inner-rect heights, box sums that fit the packed ring word.  Anything else reads the
   // integrals back (NH = 0).  HC_VAR_RING=0 pins the old route (A/B).
-  static const bool ring_ok = [] { const char* e = getenv("HC_VAR_RING"); return !e || atoi(e) != 0; }();
+  const bool ring_ok = knobs.var_ring;
   const bool ring = ring_ok && vnf && sq && R == 8 && PI_THREADS == 512 && norm_w <= 32 &&
                     (norm_h == 18 || norm_h == 22);
   // the 2.4 generation exists on the ring route only, with every grid column covered by a ring (the caller asks first:
@@ -804,7 +809,7 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
     // that still leaves room for two workgroups per CU -- if need be with the row pitch rounded to 4 instead of 64
     // words.  Then nothing reads the squares' integral and it is not stored (store_sq: a debug tap or another kernel
     // wants it); otherwise those columns keep the read-back route and their levels store it.
-    static const bool xring_ok = [] { const char* e = getenv("HC_VAR_XRING"); return !e || atoi(e) != 0; }();
+    const bool xring_ok = knobs.var_xring;
     const int extra = max_nx - VR_COLS * PI_THREADS;
     stored = store_sq;                     // without the LDS rings only the levels with read-back columns store it
     if (extra <= 0) {}
@@ -821,7 +826,14 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
       }
     }
   }
-  if (sq_stored) *sq_stored = stored;
+  if (info) {
+    info->frame_chunk = frame_chunk;
+    info->remapped = frame_chunk > 0 && nframes > frame_chunk ? 1 : 0;
+    info->tail_frames = info->remapped ? nframes % frame_chunk : 0;
+    info->rows_per_chunk = R;
+    info->sq_stored = stored;
+    info->route = !vnf ? 0 : ring ? 2 /* HC_VAR_RING */ : 3 /* HC_VAR_READBACK */;
+  }
   if (semantics == 1 && max_nx > VR_COLS * PI_THREADS && xr_pitch == 0) return (int)hipErrorInvalidValue;   // no read-back route in this generation
   if (max_w <= 2 * PI_THREADS) {
     if (ring && norm_h == 18) HC_PI(2, 18);
@@ -866,8 +878,9 @@ int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* lev
 }
 
 int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int rows, int nwaves, size_t lds_bytes,
-                   const CascadeArgs& args, int* compiled) {
+                   const CascadeArgs& args, int* compiled, int* variant) {
   if (compiled) *compiled = 0;
+  if (variant) *variant = 0;
   if (args.nbands == 0 || nframes == 0) return 0;
   // two builds of the same kernel text (cascade_body.inc): rect weights as f32, or -- when the host has shown that every
   // weight is a small integer with w0 == -1 and every weighted rect sum stays below 2^24 -- as exact integer arithmetic
@@ -877,10 +890,12 @@ int launch_cascade(hipStream_t st, int nframes, bool tree, bool segments, int ro
     const int rc = unit->launch(st, nframes, segments, rows, nwaves, lds_bytes, args);
     if (rc >= 0) {
       if (compiled) *compiled = unit->nstages;
+      if (variant) *variant = unit->p16 ? 4 /* HC_VARIANT_P16 */ : 3 /* HC_VARIANT_SPEC */;
       return rc;
     }
     if (unit->p16) return (int)hipErrorInvalidValue;   // the arguments are in that build's own formats: no other kernel may take them
   }
+  if (variant) *variant = args.int_weights ? 2 /* HC_VARIANT_INT */ : 1 /* HC_VARIANT_F32 */;
   return args.int_weights ? casc_int::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args)
                           : casc_f32::launch_cascade_ns(st, nframes, tree, segments, rows, nwaves, lds_bytes, args);
 }

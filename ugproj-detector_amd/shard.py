@@ -15,6 +15,8 @@ variable-length all-gather whose size every rank derives from the counts of the 
 boxes[K:] of its overflowing frames, padded to the largest block of any rank.  The second
 gather only happens for a batch in which some frame overflowed.
 """
+from collections.abc import Mapping
+
 import numpy as np
 
 MAX_BOXES = 64
@@ -32,12 +34,16 @@ def pack_records(frame_ids, boxes_per_frame):
     """-> int32 array [n, RECORD_INTS]: the fixed part (first K boxes) of every frame."""
     n = len(frame_ids)
     rec = np.zeros((n, RECORD_INTS), np.int32)
-    for i, (fid, b) in enumerate(zip(frame_ids, boxes_per_frame)):
-        b = np.asarray(b, np.int32).reshape(-1, 4)
-        rec[i, 0] = fid
-        rec[i, 1] = len(b)
-        k = min(len(b), MAX_BOXES)
-        rec[i, 2:2 + 4 * k] = b[:k].ravel()
+    rec[:, 0] = np.fromiter(frame_ids, np.int32, n)
+    cnt = np.fromiter((len(b) for b in boxes_per_frame), np.int32, n)
+    rec[:, 1] = cnt
+    k = np.minimum(cnt, MAX_BOXES)
+    if n and int(k.max()) > 0:
+        # all boxes of the batch as one array, then one masked scatter into the records (no per-frame row writes)
+        parts = [np.asarray(b, np.int32).reshape(-1, 4)[:MAX_BOXES] for b in boxes_per_frame]
+        flat = np.concatenate(parts)
+        kmax = int(k.max())
+        rec[:, 2:2 + 4 * kmax].reshape(n, kmax, 4)[np.arange(kmax)[None, :] < k[:, None]] = flat
     return rec
 
 
@@ -53,37 +59,78 @@ def overflow_counts(rec, world_size):
     return np.maximum(rec[:, :, 1].astype(np.int64) - MAX_BOXES, 0).sum(axis=1)
 
 
+class GatheredBoxes(Mapping):
+    """frame id -> boxes[count, 4] of one gathered batch, held COMPACT: one flat array of the boxes the fixed records carry,
+    an offset per record, and the overflow pieces of the few frames that have them.  Built with a handful of array
+    operations -- no per-record Python -- because rank 0 builds it once per step on the thread that feeds its GPU
+    (round 3 unpacked every record of every rank in a Python loop, on every rank: 6 ms per step at world 8).  Nothing is
+    materialised per frame until the consumer asks for it; an id that occurs more than once (rank padding records)
+    resolves to its first record."""
+
+    def __init__(self, rec, overflow=None):
+        rec = np.asarray(rec).reshape(-1, RECORD_INTS)
+        n = len(rec)
+        self.ids = rec[:, 0].copy()
+        self.counts = rec[:, 1].copy()
+        if n and int(self.counts.min()) < 0:
+            raise ValueError("negative box count in a gathered record")
+        k = np.minimum(self.counts, MAX_BOXES)
+        self._ofs = np.zeros(n + 1, np.int64)
+        np.cumsum(k, out=self._ofs[1:])
+        kmax = int(k.max()) if n else 0
+        body = rec[:, 2:2 + 4 * kmax].reshape(n, kmax, 4)            # only the columns some record uses
+        self._flat = body[np.arange(kmax)[None, :] < k[:, None]]      # [sum k, 4], record order; a copy: the gather buffer is reused
+        self._extra = {}
+        if overflow is not None:
+            world = len(overflow)
+            per = n // world if world else 0
+            over = np.flatnonzero(self.counts > MAX_BOXES)            # rare: a Python loop over these few is fine
+            used = [0] * world
+            for i in over.tolist():
+                r = min(i // per, world - 1) if per else 0
+                ov = np.asarray(overflow[r], np.int32).reshape(-1, 4)
+                m = int(self.counts[i]) - MAX_BOXES
+                if used[r] + m > len(ov):
+                    raise ValueError("overflow block of rank %d is shorter than its records say" % r)
+                self._extra[i] = ov[used[r]:used[r] + m].copy()
+                used[r] += m
+            for r in range(world):
+                if used[r] != len(np.asarray(overflow[r]).reshape(-1, 4)):
+                    raise ValueError("overflow block of rank %d is longer than its records say" % r)
+        self._index = None
+
+    def _lookup(self):
+        if self._index is None:
+            idx = {}
+            for i, f in enumerate(self.ids.tolist()):
+                idx.setdefault(f, i)
+            self._index = idx
+        return self._index
+
+    def record_boxes(self, i):
+        b = self._flat[self._ofs[i]:self._ofs[i + 1]]
+        e = self._extra.get(i)
+        return b if e is None else np.concatenate([b, e])
+
+    def __getitem__(self, fid):
+        return self.record_boxes(self._lookup()[fid])
+
+    def __iter__(self):
+        return iter(self._lookup())
+
+    def __len__(self):
+        return len(self._lookup())
+
+    def count(self, fid):
+        return int(self.counts[self._lookup()[fid]])
+
+
 def unpack_records(rec, overflow=None):
     """-> dict frame_id -> (count, boxes[n,4]).
     Without `overflow`, n = min(count, K) (the fixed part only).  With `overflow` -- a list of one
-    [m_r, 4] array per rank, as returned by gather_boxes -- every frame carries all `count` boxes."""
-    rec = np.asarray(rec).reshape(-1, RECORD_INTS)
-    out = {}
-    if overflow is None:
-        for r in rec:
-            cnt = int(r[1])
-            k = min(cnt, MAX_BOXES)
-            out[int(r[0])] = (cnt, r[2:2 + 4 * k].reshape(k, 4).copy())
-        return out
-    world = len(overflow)
-    per = len(rec) // world
-    for rank in range(world):
-        at = 0
-        ov = np.asarray(overflow[rank], np.int32).reshape(-1, 4)
-        for r in rec[rank * per:(rank + 1) * per]:
-            cnt = int(r[1])
-            k = min(cnt, MAX_BOXES)
-            boxes = r[2:2 + 4 * k].reshape(k, 4)
-            if cnt > MAX_BOXES:
-                extra = cnt - MAX_BOXES
-                if at + extra > len(ov):
-                    raise ValueError("overflow block of rank %d is shorter than its records say" % rank)
-                boxes = np.concatenate([boxes, ov[at:at + extra]])
-                at += extra
-            out[int(r[0])] = (cnt, boxes.copy())
-        if at != len(ov):
-            raise ValueError("overflow block of rank %d is longer than its records say" % rank)
-    return out
+    [m_r, 4] array per rank, as returned by the second all-gather -- every frame carries all `count` boxes."""
+    g = GatheredBoxes(rec, overflow)
+    return {fid: (g.count(fid), g[fid].copy()) for fid in g}
 
 
 def _dist():
@@ -114,14 +161,14 @@ def gather_boxes(frame_ids, boxes_per_frame, device=None):
     second one of the overflow blocks only when some frame of the batch has more than K boxes."""
     g = BoxGatherer(device)
     g.start(frame_ids, boxes_per_frame)
-    return g.finish()
+    return g.finish(consume=True)
 
 
 class BoxGatherer:
     """Pipelined form of gather_boxes for a caller that overlaps the exchange with its next batch:
     start() issues the collective on the current stream (device tensors for RCCL: the caller selects
     a communication stream with torch.cuda.stream) and returns at once; finish() waits for it, runs
-    the rare overflow round and returns the complete dict.  Staging buffers are persistent and
+    the rare overflow round and returns the complete mapping on rank 0.  Staging buffers are persistent and
     page-locked, so neither direction blocks the host thread that feeds the GPU."""
 
     def __init__(self, device=None):
@@ -145,7 +192,7 @@ class BoxGatherer:
             self._event = torch.cuda.Event()
             # completion flag: a sequence number copied to page-locked host memory behind the records, polled by finish().
             # Waiting on the event instead returns when the hardware queue the stream was mapped to has drained, which
-            # with the next batch already enqueued can be a whole batch later (ugproj-detector_amd/csrc/hc_api.cpp, ev_copied).
+            # with the next batch already enqueued can be a whole batch later (ugproj-detector_amd/csrc/hc_context.h, ev_copied).
             self._flag_h = torch.zeros(1, dtype=torch.int32, pin_memory=True)
             self._flag_d = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._flag_np = self._flag_h.numpy()
@@ -173,11 +220,17 @@ class BoxGatherer:
         else:
             dist.all_gather_into_tensor(self._h_out, self._h_in)
 
-    def finish(self):
+    def finish(self, consume=None):
+        """Waits for the exchange and returns the gathered batch as a GatheredBoxes mapping (frame id -> boxes) on the
+        CONSUMER, None elsewhere.  consume=None: rank 0 consumes (the tracker's side, reference
+        src/tracker/face_tracker.cc:123-148); the other ranks only read the gathered counts, which they need to size
+        the overflow round.  consume=True: this rank wants the mapping too (gather_boxes)."""
         import torch
         world, boxes, _n = self._pending
         self._pending = None
         dist = _dist()
+        if consume is None:
+            consume = dist is None or dist.get_rank() == 0
         if dist is None:
             allrec = self._rec_local
         else:
@@ -189,15 +242,24 @@ class BoxGatherer:
                         self._event.synchronize()
                         break
                     time.sleep(5e-5)
-            allrec = self._h_out.numpy().copy()
+            allrec = self._h_out.numpy()                 # the persistent buffer itself: GatheredBoxes copies what it keeps
+        return self._complete(allrec, world, boxes, consume)
+
+    def _complete(self, allrec, world, boxes, consume):
+        """what finish() does on the host once the records are in `allrec`: the gathered counts (every rank), the overflow
+        round if some frame needs it (every rank), the compact mapping (consumer only)"""
+        import torch
+        dist = _dist()
         over = overflow_counts(allrec, world)
-        self.last_records = allrec
+        self.last_records = allrec                       # valid until the next start()
         self.last_overflow_boxes = int(over.sum())
         if over.sum() == 0:
-            return {fid: b for fid, (cnt, b) in unpack_records(allrec, [np.zeros((0, 4), np.int32)] * world).items()}
+            return GatheredBoxes(allrec) if consume else None
         mine = pack_overflow(boxes)
         if dist is None:
-            blocks = [mine]
+            blocks = [mine] if world == 1 else None
+            if blocks is None:
+                raise RuntimeError("overflow round of a multi-rank batch needs the process group")
         else:
             m = int(over.max())
             buf = torch.zeros((m, 4), dtype=torch.int32)
@@ -205,10 +267,12 @@ class BoxGatherer:
             if self.device is not None:
                 buf = buf.to(self.device)
             out = torch.empty((world * m, 4), dtype=torch.int32, device=buf.device)
-            dist.all_gather_into_tensor(out, buf)
+            dist.all_gather_into_tensor(out, buf)         # every rank takes part, whoever consumes
+            if not consume:
+                return None
             out = out.cpu().numpy().reshape(world, m, 4)
             blocks = [out[r, :int(over[r])] for r in range(world)]
-        return {fid: b for fid, (cnt, b) in unpack_records(allrec, blocks).items()}
+        return GatheredBoxes(allrec, blocks) if consume else None
 
 
 # ---- on-disk form of the same records, for handing detections to the sequential tracker /
