@@ -80,6 +80,31 @@ def test_all_taps_small_planted(pkg, oracle, synth, name):
     assert sum(len(g) for g in got) > 0
 
 
+def _vnf_want(oracle, casc, frame, L):
+    """A.6a in numpy f64 from the oracle's integrals: the f32 variance factors of every scanned window of a level"""
+    img = oracle.resize_linear_exact(frame, L.h, L.w)
+    s, q = oracle.integral(img)
+    s = s.astype(np.int64)
+    q = q.view(np.uint32).astype(np.int64)
+    ys = np.arange(L.ny) * L.ystep + 1
+    xs = np.arange(L.nx) * L.ystep + 1
+    nw, nh = casc.win_w - 2, casc.win_h - 2
+
+    def rs(I, mod):
+        v = I[np.ix_(ys, xs)] - I[np.ix_(ys, xs + nw)] - I[np.ix_(ys + nh, xs)] + I[np.ix_(ys + nh, xs + nw)]
+        return v % mod if mod else v
+    valsum = rs(s, 0).astype(np.float64)
+    valsq = rs(q, 1 << 32).astype(np.float64)
+    area = float(nw * nh)
+    nf = area * valsq - valsum * valsum
+    want = np.zeros(nf.shape, np.float32)
+    pos = nf > 0
+    v = (1.0 / np.sqrt(nf[pos])).astype(np.float32)
+    v[~(area * v.astype(np.float64) < 1e-1)] = 0
+    want[pos] = v
+    return want
+
+
 def test_vnf_bits(pkg, oracle, synth):
     """A.6a: f64 sqrt / divide / f32 rounding on the device must be correctly rounded: compare the
     variance tap against a numpy f64 recomputation from the oracle's integrals, bit for bit."""
@@ -90,28 +115,8 @@ def test_vnf_bits(pkg, oracle, synth):
     ctx.configure(200, 260, 1.1, 2, (0, 0), (0, 0), max_batch=1)
     ctx.detect_host(frame[None])
     for li, L in enumerate(ctx.levels()):
-        img = oracle.resize_linear_exact(frame, L.h, L.w)
-        s, q = oracle.integral(img)
-        s = s.astype(np.int64)
-        q = q.view(np.uint32).astype(np.int64)
-        ys = np.arange(L.ny) * L.ystep + 1
-        xs = np.arange(L.nx) * L.ystep + 1
-        nw, nh = casc.win_w - 2, casc.win_h - 2
-
-        def rs(I, mod):
-            v = I[np.ix_(ys, xs)] - I[np.ix_(ys, xs + nw)] - I[np.ix_(ys + nh, xs)] + I[np.ix_(ys + nh, xs + nw)]
-            return v % mod if mod else v
-        valsum = rs(s, 0).astype(np.float64)
-        valsq = rs(q, 1 << 32).astype(np.float64)
-        area = float(nw * nh)
-        nf = area * valsq - valsum * valsum
-        want = np.zeros(nf.shape, np.float32)
-        pos = nf > 0
-        v = (1.0 / np.sqrt(nf[pos])).astype(np.float32)
-        v[~(area * v.astype(np.float64) < 1e-1)] = 0
-        want[pos] = v
         got = ctx.read_tap(0, li, pkg.TAP_VNF)
-        assert got.tobytes() == want.tobytes(), "vnf bits differ at level %d" % li
+        assert got.tobytes() == _vnf_want(oracle, casc, frame, L).tobytes(), "vnf bits differ at level %d" % li
 
 
 def test_sync_call_matches_oracle_with_row_step(pkg, oracle, synth):
@@ -485,11 +490,21 @@ def test_full_size_2160p(pkg, oracle, synth):
     grouped, raw = oc.detect(frame, 1.1, 2, (30, 30), (0, 0))
     assert np.array_equal(ctx.raw_candidates(1)[0], raw)
     assert np.array_equal(got[0], grouped) and len(grouped) >= 4
-    # integral of the widest level against the oracle (exercises the widest k_pyramid_integral variant)
-    L = ctx.levels()[0]
-    img = oracle.resize_linear_exact(frame, L.h, L.w)
-    s, q = oracle.integral(img)
-    assert np.array_equal(ctx.read_tap(0, 0, pkg.TAP_SUM), s) and np.array_equal(ctx.read_tap(0, 0, pkg.TAP_SQSUM), q)
+    # integrals of the widest level and of a mid-size one against the oracle (fused routes: four resp. two column strips per row, the
+    # carries handed across); the squares' integral only exists in global memory when a tap asks for it, so the frame runs
+    # again with the taps on, which also checks the stage counts of those two levels
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frame[None])
+    assert np.array_equal(got[0], grouped)
+    _, _, otaps = oc.detect(frame, 1.1, 2, (30, 30), (0, 0), want_taps=True)
+    for li in (0, 4):
+        L = ctx.levels()[li]
+        img = oracle.resize_linear_exact(frame, L.h, L.w)
+        s, q = oracle.integral(img)
+        assert np.array_equal(ctx.read_tap(0, li, pkg.TAP_PYRAMID), img), li
+        assert np.array_equal(ctx.read_tap(0, li, pkg.TAP_SUM), s) and np.array_equal(ctx.read_tap(0, li, pkg.TAP_SQSUM), q), li
+        assert np.array_equal(ctx.read_tap(0, li, pkg.TAP_STAGES), otaps[li]), li
+        assert ctx.read_tap(0, li, pkg.TAP_VNF).tobytes() == _vnf_want(oracle, casc, frame, L).tobytes(), li
 
 
 def test_unfused_prep_kernels_agree(pkg, oracle, synth, monkeypatch):
@@ -797,30 +812,75 @@ def test_frame_chunks_cover_every_frame_and_band(pkg, oracle, synth, monkeypatch
         assert np.array_equal(got2[f], want[f][0]), (chunks, f)
 
 
-@pytest.mark.parametrize("forced", ["1", None])
-def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, forced):
-    """Levels wider than 1024 columns (1920x1080: 1192) have no ring route in the fused prep kernel: by policy the variance
-    factors then come from k_variance behind it (faster than the kernel's read-back route: 3.8 against 4.5 ms per 96 frames);
-    HC_FUSE_VARIANCE=1 forces the read-back route, which must give the same factors, taps and boxes."""
+@pytest.mark.parametrize("route,env", [("ring_strips", {}), ("kernel", {"HC_VAR_SPLIT": "0"}),
+                                       ("readback", {"HC_VAR_SPLIT": "0", "HC_FUSE_VARIANCE": "1"})])
+def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, route, env):
+    """Levels wider than 1024 columns (1920x1080: 1192) have no ring route in the one-workgroup-per-level prep kernel.  By
+    policy such a geometry runs the column-strip form (k_pyramid_strips: every grid column on a register ring, the carry
+    handed from strip to strip); HC_VAR_SPLIT=0 restores round 3's choice -- k_variance behind the fused kernel -- and
+    HC_FUSE_VARIANCE=1 with it the kernel's read-back route.  All three must give the same integrals, factors, taps and boxes."""
     monkeypatch.setenv("HC_FUSED_PREP", "1")
-    if forced:
-        monkeypatch.setenv("HC_FUSE_VARIANCE", forced)
-    else:
-        monkeypatch.delenv("HC_FUSE_VARIANCE", raising=False)
+    for k in ("HC_VAR_SPLIT", "HC_FUSE_VARIANCE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     path = oracle.cascade_path("alt")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     frames = np.stack([synth.planted(1080, 1920, synth.frame_seed(900 + i), nfaces=5, min_size=50, max_size=300)[0] for i in range(2)])
     ctx = pkg.Context(casc)
     ctx.configure(1080, 1920, 1.1, 2, (30, 30), (0, 0), 2, 1 << 15)
     ctx.enable_stage_taps(True)
-    ctx.enable_timing(True)
     got = ctx.detect_host(frames)
-    ms = ctx.kernel_ms()
-    assert ms["k_pyramid_integral"] > 0.05
-    assert (ms["k_variance"] < 0.018) == bool(forced), ms   # the kernel takes ~0.03 ms on two frames; an empty interval still measures its event records (5-10 us)
+    info = ctx.last_launch()
+    assert info["prep_route"] == "fused" and info["variance_route"] == route, info
     for f in range(2):
         grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[f], f, 1.1, (30, 30))
         assert np.array_equal(ctx.raw_candidates(2)[f], raw) and np.array_equal(got[f], grouped)
+    # the variance factors themselves (a tap of their own): every scanned level of frame 1
+    for li, L in enumerate(ctx.levels()):
+        if L.nx and L.ny:
+            assert ctx.read_tap(1, li, pkg.TAP_VNF).tobytes() == _vnf_want(oracle, casc, frames[1], L).tobytes(), (route, li)
+
+
+@pytest.mark.parametrize("name,shape,comp", [("alt", (240, 320), 96), ("default", (240, 320), 64), ("alt2", (203, 331), 128),
+                                             ("alt_tree", (360, 640), 160), ("alt", (720, 1280), 224)])
+def test_column_strips_on_small_frames(pkg, oracle, synth, monkeypatch, name, shape, comp):
+    """The column-strip form of the fused prep kernel with NARROW strips (HC_STRIP_COMP_MAX) forced on geometries the other
+    kernel would take (HC_VAR_SPLIT=2): levels of a small frame then run through two to six strips each, so the carry
+    hand-off, the halo columns, ragged last chunks (heights that are no multiple of eight), strips without grid columns and
+    both inner-rect heights (18: alt / alt2 / alt_tree, 22: default) are all exercised at sizes the oracle finishes in
+    seconds.  Every tap of every level -- pyramid bytes, both integrals (sqsum: the tap asks for it), stage counts -- then
+    raw candidates and boxes, for a batch of five frames of mixed families."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+    monkeypatch.setenv("HC_VAR_SPLIT", "2")
+    monkeypatch.setenv("HC_STRIP_COMP_MAX", str(comp))
+    monkeypatch.setenv("HC_PI_FRAME_CHUNK", "0" if comp == 96 else "8")
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    kinds = ["planted", "texture", "noise"]
+    B = 5 if shape[0] < 700 else 10
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, shape[0], shape[1], first=4100 + i)[0] for i in range(B)])
+    ctx = pkg.Context(casc)
+    ctx.configure(shape[0], shape[1], 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 14)
+    ctx.enable_stage_taps(True)
+    got = ctx.detect_host(frames)
+    info = ctx.last_launch()
+    assert info["prep_route"] == "fused" and info["variance_route"] == "ring_strips", info
+    raws = ctx.raw_candidates(B)
+    for f in range(B):
+        if f in (0, B - 1):
+            grouped, raw = _check_frame_all_taps(pkg, oracle, ctx, oc, frames[f], f, 1.1, (30, 30))
+            for li, L in enumerate(ctx.levels()):
+                if L.nx and L.ny:
+                    assert ctx.read_tap(f, li, pkg.TAP_VNF).tobytes() == _vnf_want(oracle, casc, frames[f], L).tobytes(), (name, f, li)
+        else:
+            grouped, raw = oc.detect(frames[f], 1.1, 2, (30, 30), (0, 0))
+        assert np.array_equal(raws[f], raw) and np.array_equal(got[f], grouped), (name, f)
+    ctx.enable_stage_taps(False)           # the route the bench takes: no pyramid, no squares' integral in global memory
+    got2 = ctx.detect_host(frames)
+    assert ctx.last_launch()["sq_stored"] == 0
+    for f in range(B):
+        assert np.array_equal(got2[f], got[f]), (name, f)
 
 
 @pytest.mark.parametrize("name", ["alt", "default", "alt_tree", "alt2"])

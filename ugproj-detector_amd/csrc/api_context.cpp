@@ -36,7 +36,7 @@ Knobs knobs_from_env() {
   getb("HC_BANK_ORDER", k.bank_order);
   getb("HC_VAR_RING", k.var_ring);
   getb("HC_VAR_XRING", k.var_xring);
-  getb("HC_VAR_SPLIT", k.var_split);
+  if (const char* e = getenv("HC_VAR_SPLIT")) { k.var_split = atoi(e) != 0; k.var_split_always = atoi(e) == 2; }
   getb("HC_CV24_FUSED", k.cv24_fused);
   getb("HC_SHARE_VNF", k.share_vnf);
   getb("HC_SIDE_PRIO", k.side_prio);
@@ -45,6 +45,7 @@ Knobs knobs_from_env() {
   geti("HC_SIDE_MAX_BATCH", k.side_max_batch, 0, 1 << 20);
   geti("HC_SEG_MAX_BATCH", k.seg_max_batch, 0, 1 << 20);
   geti("HC_SEG_TILES", k.seg_tiles, 1, 255);
+  geti("HC_STRIP_COMP_MAX", k.strip_comp_max, 32, 640);
   return k;
 }
 
@@ -56,6 +57,7 @@ int sync_cache_size_from_env() {
 PrepKnobs prep_knobs(const hc_context* c) {
   PrepKnobs p;
   p.frame_chunk = c->k.pi_frame_chunk; p.var_ring = c->k.var_ring; p.var_xring = c->k.var_xring; p.var_split = c->k.var_split;
+  p.strip_comp_max = c->k.strip_comp_max;
   return p;
 }
 
@@ -69,13 +71,24 @@ PrepKnobs prep_knobs(const hc_context* c) {
 // Variance factors inside the fused prep kernel: a context on its own (a shared pass serves cascades with different windows,
 // which run k_variance each), and only where the kernel has its ring route -- the read-back route of wider levels loses to a
 // separate k_variance launch (HC_FUSE_VARIANCE=1 forces it, =0 never fuses).
-bool wants_fused_variance(const hc_context* c) {
-  if (!c->k.fuse_variance || !c->followers.empty()) return false;
-  if (c->k.fuse_variance_forced) return true;
-  int max_w = 0;
-  for (const hc::DevLevel& L : c->plan.levels) max_w = std::max(max_w, L.w);
+bool fused_kernel_has_rings(const hc_context* c) {
+  if (c->use_strips) return true;
+  int max_w = 0, max_nx = 0;
+  for (const hc::DevLevel& L : c->plan.levels) { max_w = std::max(max_w, L.w); max_nx = std::max(max_nx, L.nx); }
   const hc::Model& m = c->casc->model;
+  if (c->semantics == 1) return hc::pyramid_integral_takes_cv24(prep_knobs(c), max_w, max_nx, c->plan.cols, m.win_w - 2, m.win_h - 2);
   return hc::pyramid_integral_has_ring(prep_knobs(c), max_w, c->plan.cols, m.win_w - 2, m.win_h - 2);
+}
+
+// Variance factors inside the fused prep kernel wherever it has a ring route for them -- the one-workgroup-per-level kernel for
+// levels of at most 1024 columns, the strip kernel for any width.  Also for the leader of a shared pass: members with the
+// leader's window read these factors, members with another window run k_variance on the stored integrals.  Where neither
+// kernel has rings (an inner rect other than 18 or 22 rows) a separate k_variance launch beats the read-back route
+// (HC_FUSE_VARIANCE=1 forces that route, =0 never fuses).
+bool wants_fused_variance(const hc_context* c) {
+  if (!c->k.fuse_variance || c->leader) return false;
+  if (c->k.fuse_variance_forced) return true;
+  return fused_kernel_has_rings(c);
 }
 
 bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance) {
@@ -84,7 +97,8 @@ bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance) {
   const double equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
   if (c->k.fused_min_batch >= 0) return equiv > c->k.fused_min_batch;           // HC_FUSED_MIN_BATCH: plain threshold
   if (P.levels.empty()) return false;
-  const double A = (double)P.levels[0].w * (double)P.levels[0].h / (795.0 * 447.0);
+  // (the strip form marches down a strip of at most 640 columns, not down the whole level)
+  const double A = (double)(c->use_strips ? std::min(P.levels[0].w, 640) : P.levels[0].w) * (double)P.levels[0].h / (795.0 * 447.0);
   const double t_fused = std::max(equiv * (fused_variance ? 0.0135 : 0.0088), (fused_variance ? 0.6 : 0.4) * std::pow(A, 1.45));
   const double t_parallel = equiv * (fused_variance ? 0.0283 : 0.0233);
   return t_fused < t_parallel;
@@ -125,7 +139,7 @@ void hc_context::free_workspace() {
   followers.clear();
   void* ptrs[] = {d_frames, d_color, d_pyr, d_sum, d_sq, d_vnf, d_taps, d_levels, d_xtab, d_ytab, d_resize_items,
                   d_row_items, d_col_items, d_var_items, d_band_items[0], d_band_items[1], d_seg_items[0], d_seg_items[1], d_cand,
-                  d_count, d_ticket, d_area_xofs, d_area_xsi, d_area_xal, d_area_yofs, d_area_ysi, d_area_yal};
+                  d_count, d_ticket, d_strips, d_carry, d_strip_progress, d_area_xofs, d_area_xsi, d_area_xal, d_area_yofs, d_area_ysi, d_area_yal};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   d_frames = d_color = d_pyr = nullptr; color_bytes = 0;
   d_area_xofs = d_area_xsi = d_area_yofs = d_area_ysi = nullptr; d_area_xal = d_area_yal = nullptr; area_general = false; d_sum = d_sq = nullptr; d_vnf = nullptr; d_taps = nullptr; d_levels = nullptr;
@@ -133,6 +147,7 @@ void hc_context::free_workspace() {
   d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items[0] = d_band_items[1] = nullptr;
   d_seg_items[0] = d_seg_items[1] = nullptr;
   d_cand = nullptr; d_count = nullptr; d_ticket = nullptr;
+  d_strips = nullptr; d_carry = nullptr; d_strip_progress = nullptr; use_strips = false; strips = hc::StripPlan{};
   if (h_cand) (void)hipHostFree(h_cand);
   if (h_pub) (void)hipHostFree(h_pub);
   h_cand = nullptr; h_pub = nullptr; pub_seq = 0;
@@ -253,6 +268,20 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   ctx->min_neighbors = min_neighbors;
   ctx->cand_per_frame = cand_capacity > 0 ? cand_capacity : 4096;
   const size_t B = (size_t)max_batch;
+  if (!leader && !P.levels.empty() && ctx->k.var_split && (!cv24 || ctx->cv.fused_tables)) {
+    // column strips where the one-workgroup-per-level kernel has no ring route for this geometry (HC_VAR_SPLIT=0: never;
+    // =2: also where it has, for A/B)
+    const hc::Model& m0 = ctx->casc->model;
+    hc::plan_pyramid_strips(P.levels, P.xtab, cols, m0.win_w - 2, m0.win_h - 2, ctx->semantics, hc::prep_knobs(ctx), ctx->strips);
+    ctx->use_strips = false;
+    const bool old_ok = hc::fused_kernel_has_rings(ctx);
+    ctx->use_strips = ctx->strips.ok && (!old_ok || ctx->k.var_split_always);
+    if (ctx->use_strips) {
+      if ((rc = dev_upload(&ctx->d_strips, ctx->strips.strips))) return rc;
+      if ((rc = dev_alloc(&ctx->d_carry, B * ctx->strips.carry_words))) return rc;
+      if ((rc = dev_alloc(&ctx->d_strip_progress, B * ctx->strips.strips.size() + 1))) return rc;
+    }
+  }
   if (leader) {
     if (leader->plan.int_words != P.int_words || leader->max_batch != max_batch || leader->device != ctx->device)
       return hc::set_err(HC_ERR_STATE, "shared prep: integral layouts of leader and follower differ");
@@ -315,8 +344,8 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   if ((rc = dev_alloc(&ctx->d_ticket, 1))) return rc;
   HIPCHK(hipMemset(ctx->d_ticket, 0, sizeof(unsigned int)));
   if ((rc = hc::host_alloc_coherent((void**)&ctx->h_cand, ctx->cand_cap * sizeof(unsigned long long)))) return rc;
-  if ((rc = hc::host_alloc_coherent((void**)&ctx->h_pub, 2 * sizeof(unsigned int)))) return rc;
-  ctx->h_pub[0] = ctx->h_pub[1] = 0;
+  if ((rc = hc::host_alloc_coherent((void**)&ctx->h_pub, 4 * sizeof(unsigned int)))) return rc;
+  ctx->h_pub[0] = ctx->h_pub[1] = ctx->h_pub[2] = ctx->h_pub[3] = 0;
   ctx->pub_seq = 0;
   ctx->pending = 0;
   ctx->last_frames = 0;

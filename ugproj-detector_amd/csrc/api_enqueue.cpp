@@ -80,12 +80,25 @@ void note_prep(hc_context* c, int route, const PrepLaunchInfo* pi) {
 // Whether a 2.4 batch goes through the fused kernel: the geometry fits its ring route, every grid column has a ring, and the
 // batch is large enough for one workgroup per (level, frame) (HC_CV24_FUSED=0 pins the four separate kernels).
 bool cv24_takes_fused(const hc_context* c, int nframes) {
+  return c->k.cv24_fused && c->cv.fused_tables && (c->cv_chain || c->cv_tree_tiled) && use_fused_prep(c, nframes, true) &&
+         fused_kernel_has_rings(c);
+}
+
+// the fused prep kernel in the form this context was configured for: one workgroup per (level, frame), or per column strip
+int launch_fused_prep(hc_context* c, const Batch& b, float* vnf, bool store_sq, int semantics, PrepLaunchInfo* pi) {
   const Plan& P = c->plan;
   const Model& m = c->casc->model;
+  uint8_t* pyr = c->taps_enabled ? c->d_pyr : nullptr;
+  c->strips_ran = c->use_strips;
+  if (c->use_strips)
+    return launch_pyramid_strips(c->stream, b.nframes, c->strips, c->d_strips, b.frames, b.frame_stride, b.row_step, P.rows, P.cols,
+                                 c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq, b.int_stride, pyr, b.pyr_stride, prep_knobs(c), vnf,
+                                 b.grid_stride, store_sq, c->d_carry, c->d_strip_progress, pi, semantics);
   int max_w, max_nx;
   level_extent(P, max_w, max_nx);
-  return c->k.cv24_fused && c->cv.fused_tables && (c->cv_chain || c->cv_tree_tiled) && use_fused_prep(c, nframes, true) &&
-         pyramid_integral_takes_cv24(prep_knobs(c), max_w, max_nx, P.cols, m.win_w - 2, m.win_h - 2);
+  return launch_pyramid_integral(c->stream, b.nframes, (int)P.levels.size(), max_w, b.frames, b.frame_stride, b.row_step, P.rows, P.cols,
+                                 c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq, b.int_stride, pyr, b.pyr_stride, prep_knobs(c), vnf,
+                                 b.grid_stride, m.win_w - 2, m.win_h - 2, max_nx, store_sq, pi, semantics);
 }
 
 // ---- prep routes -------------------------------------------------------------------------------------------------
@@ -93,16 +106,8 @@ bool cv24_takes_fused(const hc_context* c, int nframes) {
 // OpenCV 2.4 through the fused prep kernel: cvResize arithmetic, integrals and the f64 variance factors in one march,
 // nothing materialised in between.
 int prep_cv24_fused(hc_context* c, Batch& b) {
-  const Plan& P = c->plan;
-  const Model& m = c->casc->model;
-  int max_w, max_nx;
-  level_extent(P, max_w, max_nx);
   PrepLaunchInfo pi;
-  if (int e = launch_pyramid_integral(c->stream, b.nframes, (int)P.levels.size(), max_w, b.frames, b.frame_stride, b.row_step, P.rows,
-                                      P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq, b.int_stride,
-                                      c->taps_enabled ? c->d_pyr : nullptr, b.pyr_stride, prep_knobs(c), (float*)c->d_vnf64, b.grid_stride,
-                                      m.win_w - 2, m.win_h - 2, max_nx, c->taps_enabled, &pi, 1))
-    return hip_fail("k_pyramid_integral (2.4)", e);
+  if (int e = launch_fused_prep(c, b, (float*)c->d_vnf64, c->taps_enabled, 1, &pi)) return hip_fail("fused prep kernel (2.4)", e);
   c->sq_valid = pi.sq_stored;
   if (b.timed) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
   b.variance_done = true;
@@ -150,18 +155,13 @@ int prep_shared_follower(hc_context* c, Batch& b) {
 // kernel's rings, one follower window of another height from a second set of rings, the rest by k_variance.  The pyramid
 // bytes only exist as a debug tap in this mode.
 int prep_fused(hc_context* c, Batch& b) {
-  const Plan& P = c->plan;
-  const Model& m = c->casc->model;
-  int max_w, max_nx;
-  level_extent(P, max_w, max_nx);
   const bool fused_variance = wants_fused_variance(c);
+  // the squares' integral leaves the chip only for somebody who reads it: a debug tap, a k_variance launch of this context
+  // (no ring route) or of a member of the shared pass whose window differs from the leader's
+  bool store_sq = c->taps_enabled || !fused_variance;
+  for (const hc_context* f : c->followers) store_sq = store_sq || !f->vnf_shared;
   PrepLaunchInfo pi;
-  if (int e = launch_pyramid_integral(c->stream, b.nframes, (int)P.levels.size(), max_w, b.frames, b.frame_stride, b.row_step, P.rows,
-                                      P.cols, c->d_levels, c->d_xtab, c->d_ytab, c->d_sum, c->d_sq, b.int_stride,
-                                      c->taps_enabled ? c->d_pyr : nullptr, b.pyr_stride, prep_knobs(c),
-                                      fused_variance ? c->d_vnf : nullptr, b.grid_stride, m.win_w - 2, m.win_h - 2, max_nx,
-                                      c->taps_enabled || !c->followers.empty(), &pi))
-    return hip_fail("k_pyramid_integral", e);
+  if (int e = launch_fused_prep(c, b, fused_variance ? c->d_vnf : nullptr, store_sq, 0, &pi)) return hip_fail("fused prep kernel", e);
   c->sq_valid = pi.sq_stored;
   if (b.timed) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
   b.variance_done = fused_variance;
@@ -305,8 +305,11 @@ int launch_cascades(hc_context* c, const Batch& b) {
 // the hardware queue they were mapped to has drained, and with several contexts alive that queue also carries another
 // context's pending work -- a software pipeline then runs one batch deep (see hc_context::ev_copied).
 int publish_results(hc_context* c) {
+  // (the strip kernel's error word sits behind the row counts of the batch it just ran with)
+  const unsigned int* strip_err = c->last_launch.variance_route == HC_VAR_RING_STRIPS || c->strips_ran
+                                      ? c->d_strip_progress + (size_t)c->last_launch.nframes * c->strips.strips.size() : nullptr;
   if (int e = launch_publish(c->stream, c->d_count, c->d_cand, (unsigned int)std::min<size_t>(c->cand_cap, 0xffffffffu), c->h_cand,
-                             c->h_pub, ++c->pub_seq, c->d_ticket))
+                             c->h_pub, ++c->pub_seq, c->d_ticket, strip_err))
     return hip_fail("k_publish", e);
   HIPCHK(hipEventRecord(c->ev_done, c->stream));
   return HC_OK;
@@ -320,6 +323,7 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   c->inflight_src = d_frames; c->inflight_frame_stride = frame_stride; c->inflight_row_step = row_step;
   c->last_launch = hc_launch_info{};
   c->last_launch.nframes = nframes;
+  c->strips_ran = false;
   for (hc_context* f : c->followers)   // the next prep pass overwrites the integrals: the followers' scans of the last one come first
     if (f->scan_in_flight) { HIPCHK(hipStreamWaitEvent(s, f->ev_done, 0)); f->scan_in_flight = false; }
   Batch b{};

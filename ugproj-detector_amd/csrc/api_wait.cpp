@@ -57,6 +57,9 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   for (int attempt = 0;; attempt++) {
     if (int rcw = wait_published(ctx)) return rcw;      // this batch's kernels are done, count and candidates are in host memory
     count = ctx->h_pub[1];
+    if (ctx->h_pub[2])
+      return set_err(HC_ERR_HIP, "k_pyramid_strips: a column strip gave up waiting for its left neighbour's carries (workgroups were "
+                                 "not started in id order?); HC_VAR_SPLIT=0 avoids the strip form");
     if (ctx->k.debug_max_stages > 0 && count > ctx->cand_cap) count = 0;   // timing experiments only
     if (count <= ctx->cand_cap) break;
     // More raw candidates than the workspace holds (the counter keeps counting past the capacity, so the need is

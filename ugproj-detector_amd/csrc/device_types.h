@@ -28,6 +28,22 @@ struct DevLevel {
 
 struct WorkItem { int32_t level, a, b; };
 
+// One workgroup's share of a pyramid level in k_pyramid_strips: a column strip.  The strip STORES the integrals of
+// pixel columns [c0, c1), COMPUTES pixels of [c0, ce) -- norm_w columns of halo, so that the inner-rect box sums of
+// its own windows need nothing from the neighbour -- and emits the variance factors of grid columns [g0, g1).
+// Strips of a level are listed left to right; every strip but the last publishes, per row, the finished integral
+// values of its last stored column (sum, sqsum) for its right neighbour to add (the only cross-strip dependency).
+struct DevStrip {
+  int32_t level;
+  int32_t c0, c1, ce;
+  int32_t g0, g1;
+  int32_t sx0, sxn;        // staged source bytes of a row: [sx0, sx0 + sxn), both multiples of 4
+  int32_t left;            // index of the left neighbour strip, -1: none
+  int32_t has_right;       // publishes carries for a right neighbour
+  int32_t carry_ofs;       // word offset of this strip's published rows inside one frame's carry block ((h + 1) x 2 words)
+  int32_t pad;
+};
+
 // LDS tile geometry of the cascade kernel for one ystep.
 struct TileGeom {
   int32_t pitch;   // words per tile row

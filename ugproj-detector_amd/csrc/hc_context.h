@@ -60,7 +60,9 @@ struct Knobs {
   int pi_frame_chunk = 32;       // HC_PI_FRAME_CHUNK: k_pyramid_integral walks the batch in chunks of this many frames (0: level-major)
   bool var_ring = true;          // HC_VAR_RING=0: variance factors by read-back instead of the register rings
   bool var_xring = true;         // HC_VAR_XRING=0: grid columns beyond the register rings read back instead of LDS rings
-  bool var_split = true;         // HC_VAR_SPLIT=0: levels wider than the ring kernel never take the two-strip form
+  bool var_split = true;         // HC_VAR_SPLIT=0: never the column-strip form of the fused prep kernel (k_pyramid_strips)
+  int strip_comp_max = 640;      // HC_STRIP_COMP_MAX: pixel columns a strip computes at most (tests: small values cut small frames into strips)
+  bool var_split_always = false; // HC_VAR_SPLIT=2: the strip form also where the one-workgroup-per-level kernel has rings (A/B)
   bool cv24_fused = true;        // HC_CV24_FUSED=0: 2.4 semantics always through the four separate prep kernels
   bool share_vnf = true;         // HC_SHARE_VNF=0: every member of a shared pass computes its own variance factors
   // ---- small-batch routes, streams, host
@@ -175,6 +177,14 @@ struct hc_context {
   hc::DevLevel* d_levels = nullptr;
   uint32_t* d_xtab = nullptr;
   uint32_t* d_ytab = nullptr;
+  // column strips of the fused prep kernel (k_pyramid_strips): geometries the one-workgroup-per-level kernel has no ring route
+  // for (levels wider than 1024 columns, frames whose source rows do not fit its staging).  use_strips: decided at configure time
+  hc::StripPlan strips;
+  bool use_strips = false;
+  bool strips_ran = false;                 // the batch in flight went through k_pyramid_strips
+  hc::DevStrip* d_strips = nullptr;
+  uint32_t* d_carry = nullptr;             // per frame: the finished last-column integrals a strip hands to its right neighbour
+  unsigned int* d_strip_progress = nullptr;   // per (frame, strip): rows published; + one error word
   hc::WorkItem *d_resize_items = nullptr, *d_row_items = nullptr, *d_col_items = nullptr, *d_var_items = nullptr,
                *d_band_items[2] = {nullptr, nullptr}, *d_seg_items[2] = {nullptr, nullptr};
   int n_seg_items[2] = {0, 0};           // bands cut into segments of seg_tiles tiles: the work list of small batches
@@ -270,6 +280,7 @@ int plugin_load(const char* path);
 
 // ---- api_context.cpp: route policy
 bool wants_fused_variance(const hc_context* c);
+bool fused_kernel_has_rings(const hc_context* c);   // either form of the fused kernel produces this context's factors from rings
 bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance);
 PrepKnobs prep_knobs(const hc_context* c);
 int ensure_frames(hc_context* c);

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #include "device_types.h"
 
@@ -61,7 +62,7 @@ int spec_register(const SpecUnit* u);
 constexpr int SPEC_PLUGIN_ABI = 5 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
 
 // k_pyramid_integral: the context's knobs that reach the launcher, and what a launch then did (hc_context_last_launch)
-struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; };
+struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; int strip_comp_max = 640; };
 struct PrepLaunchInfo {
   int frame_chunk = 0;     // chunk size the kernel was given
   int remapped = 0;        // 1: grid wider than the chunk, the workgroup remap ran
@@ -87,6 +88,24 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
                             uint8_t* pyr, size_t pyr_stride, const PrepKnobs& knobs, float* vnf = nullptr, size_t grid_stride = 0,
                             int norm_w = 0, int norm_h = 0, int max_nx = 0, bool store_sq = true, PrepLaunchInfo* info = nullptr,
                             int semantics = 0);
+// ---- the same fused pass for levels of any width (k_pyramid_strips): a level is cut into column strips, one workgroup each
+struct StripPlan {
+  std::vector<DevStrip> strips;    // widest levels first, strips of a level left to right
+  int lds_pitch = 0, src_pitch = 0;
+  size_t lds_bytes = 0;
+  size_t carry_words = 0;          // per frame
+  int norm_w = 0, norm_h = 0;
+  bool ok = false;                 // false: this geometry has no strip route (odd inner rect, table format, LDS)
+};
+// levels / xtab: the host copies of the plan (scale_plan.h); semantics 1: the 2.4 table packing
+void plan_pyramid_strips(const std::vector<DevLevel>& levels, const std::vector<uint32_t>& xtab, int cols, int norm_w, int norm_h,
+                         int semantics, const PrepKnobs& knobs, StripPlan& out);
+// carry: nframes x plan.carry_words words; progress: nframes x strips words + 1 error word at the end (zeroed by the launcher)
+int launch_pyramid_strips(hipStream_t st, int nframes, const StripPlan& plan, const DevStrip* d_strips, const uint8_t* frames,
+                          size_t frame_stride, size_t row_step, int rows, int cols, const DevLevel* levels, const uint32_t* xtab,
+                          const uint32_t* ytab, uint32_t* sum, uint32_t* sq, size_t int_stride, uint8_t* pyr, size_t pyr_stride,
+                          const PrepKnobs& knobs, float* vnf, size_t grid_stride, bool store_sq, uint32_t* carry,
+                          unsigned int* progress, PrepLaunchInfo* info, int semantics);
 bool pyramid_integral_has_ring(const PrepKnobs& knobs, int max_w, int cols, int norm_w, int norm_h);
 bool pyramid_integral_takes_cv24(const PrepKnobs& knobs, int max_w, int max_nx, int cols, int norm_w, int norm_h);
 // FaceDetector::detectFaces pre-steps (face_kernels.hip): BGR -> mask + equalised, masked gray
@@ -112,7 +131,8 @@ int launch_integral_rows(hipStream_t st, int nframes, int nitems, const uint8_t*
 int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                          uint32_t* sum, uint32_t* sq, size_t int_stride);
 int launch_publish(hipStream_t st, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
-                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq, unsigned int* ticket);
+                   unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq, unsigned int* ticket,
+                   const unsigned int* err = nullptr);
 int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride);
