@@ -109,7 +109,7 @@ def test_bench_shape_160_frames_every_chunk(pkg, oracle, synth):
     got = ctx.wait(B)
     raws = ctx.raw_candidates(B)
     info = ctx.last_launch()
-    assert info["prep_route"] == "fused" and info["variance_route"] == "ring" and info["nframes"] == B, info
+    assert info["prep_route"] == "fused" and info["variance_route"] == "ring_strips" and info["nframes"] == B, info
     assert (info["pi_frame_chunk"], info["pi_remapped"], info["pi_tail_frames"]) == (32, 1, 0), info
     assert (info["casc_frame_chunk"], info["casc_remapped"], info["casc_tail_frames"]) == (128, 1, 32), info
     assert info["variant"] == ("p16", "spec") and info["segments"] == 0 and info["sq_stored"] == 0, info

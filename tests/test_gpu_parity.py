@@ -233,10 +233,15 @@ def test_batch_determinism_and_device_input(pkg, oracle, synth):
         assert np.array_equal(x, y)
 
 
-def test_full_size_720p_alt(pkg, oracle, synth):
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_full_size_720p_alt(pkg, oracle, synth, monkeypatch, split):
     """BASELINE config #2 at full size: 1280x720, alt, sf 1.1, minNeighbors 2, minSize 30.
     Boxes + raw candidates + per-window stage counts against the oracle on one planted frame and
-    one noise frame (oracle ~1 s per frame)."""
+    one noise frame (oracle ~1 s per frame).  With the fused prep pinned this runs the column-strip kernel (default) and,
+    with HC_VAR_SPLIT=0, round 3's one-workgroup-per-level kernel with its register and LDS rings (two levels of this ladder
+    have more than 512 grid columns), which stays in the library as the A/B reference; the variance factors of four levels
+    are compared as a tap of their own."""
+    monkeypatch.setenv("HC_VAR_SPLIT", split)
     path = oracle.cascade_path("alt")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     frames = np.stack([synth.planted(720, 1280, synth.frame_seed(0))[0], synth.noise(720, 1280, synth.frame_seed(1))])
@@ -254,6 +259,12 @@ def test_full_size_720p_alt(pkg, oracle, synth):
         assert np.array_equal(raws[f], raw)
         assert np.array_equal(got[f], grouped)
     assert len(got[0]) >= 5
+    info = ctx.last_launch()
+    if info["prep_route"] == "fused":
+        assert info["variance_route"] == ("ring_strips" if split == "1" else "ring"), info
+    for li in (0, 3, 4, 20):
+        L = ctx.levels()[li]
+        assert ctx.read_tap(1, li, pkg.TAP_VNF).tobytes() == _vnf_want(oracle, casc, frames[1], L).tobytes(), (split, li)
 
 
 def test_cpp_shim_matches_oracle(pkg, oracle, synth, tmp_path):
@@ -754,6 +765,8 @@ def test_cpp_throughput_demo(pkg, oracle, synth, tmp_path, pool):
     {"HC_BANK_ORDER": "0"},                             # sparse finish reads the stumps in the dense path's order
     {"HC_BAND_WAVES1": "8", "HC_BAND_WAVES2": "4"},     # swapped workgroup shapes
     {"HC_BAND_WAVES1": "8", "HC_BAND_ROWS1": "32", "HC_BAND_WAVES2": "4", "HC_BAND_ROWS2": "8"},
+    {"HC_VAR_SPLIT": "0", "HC_FUSED_PREP": "1"},        # the one-workgroup-per-level prep kernel (round 3's) with its rings
+    {"HC_VAR_SPLIT": "0", "HC_VAR_RING": "0", "HC_FUSED_PREP": "1"},   # ... and with its read-back route
 ])
 def test_tuning_knobs_do_not_change_results(pkg, oracle, synth, monkeypatch, knobs):
     """Every tuning knob (read when a context is created) must leave all taps bit-exact."""
@@ -845,14 +858,13 @@ def test_wide_levels_variance_routes(pkg, oracle, synth, monkeypatch, route, env
 @pytest.mark.parametrize("name,shape,comp", [("alt", (240, 320), 96), ("default", (240, 320), 64), ("alt2", (203, 331), 128),
                                              ("alt_tree", (360, 640), 160), ("alt", (720, 1280), 224)])
 def test_column_strips_on_small_frames(pkg, oracle, synth, monkeypatch, name, shape, comp):
-    """The column-strip form of the fused prep kernel with NARROW strips (HC_STRIP_COMP_MAX) forced on geometries the other
-    kernel would take (HC_VAR_SPLIT=2): levels of a small frame then run through two to six strips each, so the carry
+    """The column-strip form of the fused prep kernel with NARROW strips (HC_STRIP_COMP_MAX) on small frames, whose levels
+    a strip of the default width would take whole: every level then runs through two to six strips, so the carry
     hand-off, the halo columns, ragged last chunks (heights that are no multiple of eight), strips without grid columns and
     both inner-rect heights (18: alt / alt2 / alt_tree, 22: default) are all exercised at sizes the oracle finishes in
     seconds.  Every tap of every level -- pyramid bytes, both integrals (sqsum: the tap asks for it), stage counts -- then
     raw candidates and boxes, for a batch of five frames of mixed families."""
     monkeypatch.setenv("HC_FUSED_PREP", "1")
-    monkeypatch.setenv("HC_VAR_SPLIT", "2")
     monkeypatch.setenv("HC_STRIP_COMP_MAX", str(comp))
     monkeypatch.setenv("HC_PI_FRAME_CHUNK", "0" if comp == 96 else "8")
     path = oracle.cascade_path(name)

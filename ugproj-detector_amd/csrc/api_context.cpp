@@ -36,7 +36,7 @@ Knobs knobs_from_env() {
   getb("HC_BANK_ORDER", k.bank_order);
   getb("HC_VAR_RING", k.var_ring);
   getb("HC_VAR_XRING", k.var_xring);
-  if (const char* e = getenv("HC_VAR_SPLIT")) { k.var_split = atoi(e) != 0; k.var_split_always = atoi(e) == 2; }
+  getb("HC_VAR_SPLIT", k.var_split);
   getb("HC_CV24_FUSED", k.cv24_fused);
   getb("HC_SHARE_VNF", k.share_vnf);
   getb("HC_SIDE_PRIO", k.side_prio);
@@ -45,7 +45,7 @@ Knobs knobs_from_env() {
   geti("HC_SIDE_MAX_BATCH", k.side_max_batch, 0, 1 << 20);
   geti("HC_SEG_MAX_BATCH", k.seg_max_batch, 0, 1 << 20);
   geti("HC_SEG_TILES", k.seg_tiles, 1, 255);
-  geti("HC_STRIP_COMP_MAX", k.strip_comp_max, 32, 640);
+  geti("HC_STRIP_COMP_MAX", k.strip_comp_max, 0, 1024);
   return k;
 }
 
@@ -98,7 +98,7 @@ bool use_fused_prep(const hc_context* c, int nframes, bool fused_variance) {
   if (c->k.fused_min_batch >= 0) return equiv > c->k.fused_min_batch;           // HC_FUSED_MIN_BATCH: plain threshold
   if (P.levels.empty()) return false;
   // (the strip form marches down a strip of at most 640 columns, not down the whole level)
-  const double A = (double)(c->use_strips ? std::min(P.levels[0].w, 640) : P.levels[0].w) * (double)P.levels[0].h / (795.0 * 447.0);
+  const double A = (double)(c->use_strips ? std::min(P.levels[0].w, c->strips.lds_pitch) : P.levels[0].w) * (double)P.levels[0].h / (795.0 * 447.0);
   const double t_fused = std::max(equiv * (fused_variance ? 0.0135 : 0.0088), (fused_variance ? 0.6 : 0.4) * std::pow(A, 1.45));
   const double t_parallel = equiv * (fused_variance ? 0.0283 : 0.0233);
   return t_fused < t_parallel;
@@ -269,13 +269,12 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   ctx->cand_per_frame = cand_capacity > 0 ? cand_capacity : 4096;
   const size_t B = (size_t)max_batch;
   if (!leader && !P.levels.empty() && ctx->k.var_split && (!cv24 || ctx->cv.fused_tables)) {
-    // column strips where the one-workgroup-per-level kernel has no ring route for this geometry (HC_VAR_SPLIT=0: never;
-    // =2: also where it has, for A/B)
+    // The fused prep kernel runs in its column-strip form wherever a strip plan exists for the geometry (any frame width;
+    // inner rects of 18 or 22 rows, i.e. the 20 x 20 and 24 x 24 windows of the stock cascades); HC_VAR_SPLIT=0 keeps the
+    // one-workgroup-per-level kernel.
     const hc::Model& m0 = ctx->casc->model;
     hc::plan_pyramid_strips(P.levels, P.xtab, cols, m0.win_w - 2, m0.win_h - 2, ctx->semantics, hc::prep_knobs(ctx), ctx->strips);
-    ctx->use_strips = false;
-    const bool old_ok = hc::fused_kernel_has_rings(ctx);
-    ctx->use_strips = ctx->strips.ok && (!old_ok || ctx->k.var_split_always);
+    ctx->use_strips = ctx->strips.ok;
     if (ctx->use_strips) {
       if ((rc = dev_upload(&ctx->d_strips, ctx->strips.strips))) return rc;
       if ((rc = dev_alloc(&ctx->d_carry, B * ctx->strips.carry_words))) return rc;

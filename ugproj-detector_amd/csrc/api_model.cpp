@@ -465,17 +465,19 @@ int upload_model(hc_context* c) {
   if ((rc = dev_upload(&c->d_trees, tr))) return rc;
   if ((rc = dev_upload(&c->d_leaves, m.leaves))) return rc;
   // ---- 16-bit-tile build of the scan-step-1 launch, when the cascade and the launch shape qualify
-  if (!cv24 && c->k.allow_p16 && c->k.allow_spec && c->int_weights && m.is_stump() && c->k.band_rows[0] == 16 && c->k.band_waves[0] == 4 &&
+  const bool p16_shape = (c->k.band_rows[0] == 16 && c->k.band_waves[0] == 4) || (c->k.band_rows[0] == 32 && c->k.band_waves[0] == 8);
+  if (!cv24 && c->k.allow_p16 && c->k.allow_spec && c->int_weights && m.is_stump() && p16_shape &&
       c->k.row_stages <= 2 && !st.empty() && st[0].exact == 2) {
+    const int prows = c->k.band_rows[0];
     int pst = 0;
     const int id = hc::spec_lookup(model_hash(m), m.win_w, m.win_h, &pst, true);
     hc::Model m16;
     if (id > 0 && p16_model(m, m16)) {
-      hc::TileGeom g = make_geom(m, 1, 16);
+      hc::TileGeom g = make_geom(m, 1, prows);
       g.pitch = (g.cols + 1) & ~1;
       const size_t tile_bytes = ((size_t)g.pitch * g.rows * 2 + 7) & ~(size_t)7;
-      const size_t fixed = (size_t)16 * hc::TILE_POS * (4 + 6 + 2) + 264;  // vnf | copy B (6 KB; the list later) | bank matrix | 64 counters + ticket
-      if (tile_bytes <= (size_t)16 * hc::TILE_POS * 6 && node_kinds_fit_p16(m16)) {
+      const size_t fixed = (size_t)prows * hc::TILE_POS * (4 + 6 + 2) + 264;  // vnf | copy B (6 bytes per window; the list later) | bank matrix | 64 counters + ticket
+      if (tile_bytes <= (size_t)prows * hc::TILE_POS * 6 && node_kinds_fit_p16(m16)) {
         c->geom_p16 = g;
         c->tile_words_p16 = (int)(tile_bytes / 4);
         c->lds_bytes_p16 = fixed + tile_bytes;

@@ -60,9 +60,10 @@ struct Knobs {
   int pi_frame_chunk = 32;       // HC_PI_FRAME_CHUNK: k_pyramid_integral walks the batch in chunks of this many frames (0: level-major)
   bool var_ring = true;          // HC_VAR_RING=0: variance factors by read-back instead of the register rings
   bool var_xring = true;         // HC_VAR_XRING=0: grid columns beyond the register rings read back instead of LDS rings
-  bool var_split = true;         // HC_VAR_SPLIT=0: never the column-strip form of the fused prep kernel (k_pyramid_strips)
-  int strip_comp_max = 640;      // HC_STRIP_COMP_MAX: pixel columns a strip computes at most (tests: small values cut small frames into strips)
-  bool var_split_always = false; // HC_VAR_SPLIT=2: the strip form also where the one-workgroup-per-level kernel has rings (A/B)
+  bool var_split = true;         // HC_VAR_SPLIT=0: never the column-strip form of the fused prep kernel (k_pyramid_strips): the
+                                 // one-workgroup-per-level kernel with its own ring / read-back / k_variance routes (round 3)
+  int strip_comp_max = 0;        // HC_STRIP_COMP_MAX: pixel columns a strip computes at most; 0: the widest that fits (tests: small values
+                                 // cut small frames into several strips)
   bool cv24_fused = true;        // HC_CV24_FUSED=0: 2.4 semantics always through the four separate prep kernels
   bool share_vnf = true;         // HC_SHARE_VNF=0: every member of a shared pass computes its own variance factors
   // ---- small-batch routes, streams, host

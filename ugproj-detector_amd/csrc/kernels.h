@@ -62,7 +62,7 @@ int spec_register(const SpecUnit* u);
 constexpr int SPEC_PLUGIN_ABI = 5 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
 
 // k_pyramid_integral: the context's knobs that reach the launcher, and what a launch then did (hc_context_last_launch)
-struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; int strip_comp_max = 640; };
+struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; int strip_comp_max = 0; };
 struct PrepLaunchInfo {
   int frame_chunk = 0;     // chunk size the kernel was given
   int remapped = 0;        // 1: grid wider than the chunk, the workgroup remap ran

@@ -1044,18 +1044,16 @@ int launch_pyramid_integral(hipStream_t st, int nframes, int nlevels, int max_w,
 // pixel columns (stored columns + the norm_w halo: the LDS row pitch), (ii) owns at most PI_THREADS grid columns (one
 // register ring per thread) and (iii) samples at most STRIP_SPAN_MAX bytes of a source row (the staging rows of a
 // wavefront; what made whole-row staging cost 61 KB at 3840 columns).
-constexpr int STRIP_COMP_MAX = 640;
+constexpr int STRIP_COMP_MAX = 1024;  // hard cap (two stored columns per thread); the default comes with the knobs (640)
 constexpr int STRIP_SPAN_MAX = 2048;
 
-void plan_pyramid_strips(const std::vector<DevLevel>& levels, const std::vector<uint32_t>& xtab, int cols, int norm_w, int norm_h,
-                         int semantics, const PrepKnobs& knobs, StripPlan& out) {
+static void plan_strips_at_width(const std::vector<DevLevel>& levels, const std::vector<uint32_t>& xtab, int cols, int norm_w, int norm_h,
+                                 int semantics, int comp_max_wanted, StripPlan& out) {
   out = StripPlan{};
   out.norm_w = norm_w; out.norm_h = norm_h;
   if (PI_THREADS != 512 || norm_w > 32 || norm_w < 1 || (norm_h != 18 && norm_h != 22) || levels.empty()) return;
   const auto src_col = [&](const DevLevel& L, int x) { const uint32_t t = xtab[L.xtab_ofs + x]; return semantics == 1 ? (int)(t & 0x1fffu) : (int)(t >> 9); };
-  // HC_STRIP_COMP_MAX (tests): narrower strips, so that small frames run through several of them; never below what one
-  // window's box sums need
-  const int comp_max = std::min(STRIP_COMP_MAX, std::max(knobs.strip_comp_max, norm_w + 2 + 8));
+  const int comp_max = std::min(STRIP_COMP_MAX, std::max(comp_max_wanted, norm_w + 2 + 8));   // never below what one window's box sums need
   int max_comp = 0, max_span = 0;
   size_t carry_words = 0;
   for (size_t li = 0; li < levels.size(); li++) {
@@ -1103,6 +1101,19 @@ void plan_pyramid_strips(const std::vector<DevLevel>& levels, const std::vector<
   out.lds_bytes = ((size_t)(2 * (PI_THREADS / 64) + 1) * out.lds_pitch + 2 * (PI_THREADS / 64)) * 4 + (size_t)(PI_THREADS / 64) * 2 * out.src_pitch;
   out.carry_words = (carry_words + 1) & ~(size_t)1;
   out.ok = out.lds_bytes <= 81920u;                                   // two workgroups per CU
+}
+
+// The widest strips whose workgroup still fits two to a CU: 832 computed columns take a 1280x720 ladder as single strips
+// but for its two widest scan-step-1 levels (and run it faster than the one-workgroup-per-level kernel: 4.43 against 4.53
+// ms per 512 frames, no register spills); 1920- and 3840-column frames need more LDS for their source spans and get 640.
+// HC_STRIP_COMP_MAX pins a width (tests: narrow strips on small frames).
+void plan_pyramid_strips(const std::vector<DevLevel>& levels, const std::vector<uint32_t>& xtab, int cols, int norm_w, int norm_h,
+                         int semantics, const PrepKnobs& knobs, StripPlan& out) {
+  if (knobs.strip_comp_max > 0) { plan_strips_at_width(levels, xtab, cols, norm_w, norm_h, semantics, knobs.strip_comp_max, out); return; }
+  for (int wdt : {832, 640, 512, 384}) {
+    plan_strips_at_width(levels, xtab, cols, norm_w, norm_h, semantics, wdt, out);
+    if (out.ok) return;
+  }
 }
 
 int launch_pyramid_strips(hipStream_t st, int nframes, const StripPlan& plan, const DevStrip* d_strips, const uint8_t* frames,

@@ -38,11 +38,19 @@ namespace casc_p16 {
 #undef A
 
 static int launch_unit(hipStream_t st, int nframes, bool segments, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
-  if (segments || args.g.half != 0 || rows != 16 || nwaves != 4 || args.g.pitch != Spec_altp::pitch1 || args.row_stages > Spec_altp::pair_stages)
-    return -1;
+  if (segments || args.g.half != 0 || args.g.pitch != Spec_altp::pitch1 || args.row_stages > Spec_altp::pair_stages) return -1;
   const dim3 grid(nframes, args.nbands);
-  if (args.taps) hipLaunchKernelGGL((k_cascade<false, 16, 4, false, true, Spec_altp, 1>), grid, dim3(256), lds_bytes, st, args);
-  else hipLaunchKernelGGL((k_cascade<false, 16, 4, false, false, Spec_altp, 1>), grid, dim3(256), lds_bytes, st, args);
+  // the production shape (16 grid rows, 4 wavefronts: 1024 windows per tile) and the double tile (32 rows, 8 wavefronts: the
+  // generated offsets depend on the tile's pitch only, not on its height)
+  if (rows == 16 && nwaves == 4) {
+    if (args.taps) hipLaunchKernelGGL((k_cascade<false, 16, 4, false, true, Spec_altp, 1>), grid, dim3(256), lds_bytes, st, args);
+    else hipLaunchKernelGGL((k_cascade<false, 16, 4, false, false, Spec_altp, 1>), grid, dim3(256), lds_bytes, st, args);
+  } else if (rows == 32 && nwaves == 8) {
+    if (args.taps) hipLaunchKernelGGL((k_cascade<false, 32, 8, false, true, Spec_altp, 1>), grid, dim3(512), lds_bytes, st, args);
+    else hipLaunchKernelGGL((k_cascade<false, 32, 8, false, false, Spec_altp, 1>), grid, dim3(512), lds_bytes, st, args);
+  } else {
+    return -1;
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
