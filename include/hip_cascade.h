@@ -321,7 +321,8 @@ typedef enum hc_variant {
   HC_VARIANT_P16 = 4,         /* compiled early stages on the 16-bit tile, two windows per lane in row form  */
   HC_VARIANT_CV24 = 5,        /* 2.4 semantics on the tiled band kernel (stage chain)                        */
   HC_VARIANT_CV24_TREE = 6,   /* 2.4 semantics, stage tree swept in preorder on the tiles                    */
-  HC_VARIANT_CV24_WINDOW = 7  /* 2.4 semantics, window-at-a-time kernel                                      */
+  HC_VARIANT_CV24_WINDOW = 7, /* 2.4 semantics, window-at-a-time kernel                                      */
+  HC_VARIANT_CV24_CHAINS = 8  /* 2.4 semantics, stage tree as alternative chains on the tiled band kernel    */
 } hc_variant;
 typedef enum hc_prep_route {
   HC_PREP_NONE = 0, HC_PREP_FUSED = 1, HC_PREP_PARALLEL = 2, HC_PREP_SHARED_FOLLOWER = 3,

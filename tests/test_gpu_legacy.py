@@ -102,7 +102,7 @@ def test_cv24_colour_input_through_the_cpp_shim(pkg, oracle, synth, tmp_path):
     assert not np.array_equal(want24, want4)
 
 
-@pytest.mark.parametrize("route", ["separate", "fused"])
+@pytest.mark.parametrize("route", ["separate", "fused", "fused_sweep"])
 @pytest.mark.parametrize("name", ["alt", "alt2", "default", "alt_tree"])
 def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     """The 2.4 evaluation as a batched, device-resident path (hc_context_set_semantics): 6 frames of mixed families in one
@@ -111,7 +111,14 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     Both prep routes: the four separate kernels (cvResize pyramid, two-pass integrals, k_cv24_variance) and the fused
     k_pyramid_integral<.., SEM = 1> that bench.py's batches take by policy (cvResize arithmetic, integrals and f64
     factors in one march); with taps on, the fused kernel also leaves the pyramid bytes and both integrals to compare."""
-    monkeypatch.setenv("HC_FUSED_PREP", "1" if route == "fused" else "0")
+    # alt_tree's stage tree (a spine of five stages, then two chains of 18 and 21 stages, the second tried when the first
+    # fails) runs as ALTERNATIVE CHAINS on the chain kernel by default -- segment after segment over the same tile, failures
+    # of a chain stage collected for the next chain -- and as the preorder sweep (k_cv24_tree) with HC_CV24_SEG=0: the
+    # route "fused_sweep", which only exists for that cascade.
+    if route == "fused_sweep" and name != "alt_tree":
+        pytest.skip("the other cascades' stages form a chain")
+    monkeypatch.setenv("HC_FUSED_PREP", "0" if route == "separate" else "1")
+    monkeypatch.setenv("HC_CV24_SEG", "0" if route == "fused_sweep" else "1")
     path = oracle.cascade_path(name)
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     kinds = ["planted", "texture", "noise"]
@@ -127,15 +134,15 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     got = ctx.detect_host(frames)
     ms = ctx.kernel_ms()
     # (an interval without a kernel still measures its event records, ~5-10 us: compare with the kernel that did run)
-    if route == "fused":
+    if route != "separate":
         assert ms["k_integral_rows"] + ms["k_integral_cols"] < 0.5 * ms["k_pyramid_integral"], ms
     else:
         assert ms["k_integral_rows"] + ms["k_integral_cols"] > 0.5 * ms["k_pyramid_integral"], ms
     raws = ctx.raw_candidates(6)
     nraw = 0
     info = ctx.last_launch()
-    assert info["prep_route"] == ("cv24_fused" if route == "fused" else "cv24_parallel"), info
-    assert info["variant"][0] in (("cv24_tree",) if name == "alt_tree" else ("cv24",)), info
+    assert info["prep_route"] == ("cv24_parallel" if route == "separate" else "cv24_fused"), info
+    assert info["variant"][0] == (("cv24_tree" if route == "fused_sweep" else "cv24_chains") if name == "alt_tree" else "cv24"), info
     # the f32 variance-factor tap of the >= 4 layout does not exist in this mode (f64 factors live in another buffer): the
     # read must fail cleanly instead of copying from a one-element stub
     with pytest.raises(pkg.HipCascadeError) as ei:

@@ -70,7 +70,7 @@ class LaunchInfo(C.Structure):
                 ("side_stream", C.c_int32), ("sq_stored", C.c_int32), ("nframes", C.c_int32)]
 
 
-VARIANT_NAMES = ("none", "f32", "int", "spec", "p16", "cv24", "cv24_tree", "cv24_window")       # hc_variant
+VARIANT_NAMES = ("none", "f32", "int", "spec", "p16", "cv24", "cv24_tree", "cv24_window", "cv24_chains")       # hc_variant
 PREP_NAMES = ("none", "fused", "parallel", "shared_follower", "cv24_fused", "cv24_parallel")   # hc_prep_route
 VARIANCE_NAMES = ("none", "kernel", "ring", "readback", "leader", "ring_strips", "cv24_kernel")   # hc_variance_route
 

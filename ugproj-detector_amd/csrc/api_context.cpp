@@ -38,6 +38,7 @@ Knobs knobs_from_env() {
   getb("HC_VAR_XRING", k.var_xring);
   getb("HC_VAR_SPLIT", k.var_split);
   getb("HC_CV24_FUSED", k.cv24_fused);
+  getb("HC_CV24_SEG", k.cv24_seg);
   getb("HC_SHARE_VNF", k.share_vnf);
   getb("HC_SIDE_PRIO", k.side_prio);
   getb("HC_COPY_PRIO", k.copy_prio);

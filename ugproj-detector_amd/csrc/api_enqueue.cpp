@@ -272,7 +272,14 @@ int launch_cascades(hc_context* c, const Batch& b) {
     A.tree_pass = c->d_tree_pass; A.tree_fail = c->d_tree_fail; A.tree_order = c->d_tree_order;
     hipStream_t ks = side && k == 1 ? c->side_stream : s;
     int compiled = 0, variant = HC_VARIANT_NONE, e;
-    if (c->semantics == 1 && !c->cv_chain) {
+    if (c->semantics == 1 && !c->cv_chain && c->cv_seg) {
+      // the stage tree as alternative chains on the chain kernel: stage tables in evaluation order, segment bounds
+      A.stages = c->d_stages_seg; A.kinds = c->d_kinds_seg;
+      A.nseg = c->seg_n; A.spine_len = c->seg_spine;
+      for (int g = 0; g < 4; g++) A.seg_end[g] = c->seg_end[g];
+      e = launch_cascade_cv24(ks, b.nframes, false, c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A);
+      variant = HC_VARIANT_CV24_CHAINS;
+    } else if (c->semantics == 1 && !c->cv_chain) {
       e = launch_cv24_tree(ks, b.nframes, c->k.band_waves[k], c->lds_bytes[k], A);
       variant = HC_VARIANT_CV24_TREE;
     } else if (c->semantics == 1) {

@@ -189,9 +189,10 @@ unsigned long long model_hash(const hc::Model& m) {
 void free_model_tables(hc_context* c) {
   void* ptrs[] = {c->d_nodes[0], c->d_nodes[1], c->d_nodes_sparse[0], c->d_nodes_sparse[1], c->d_stages, c->d_trees, c->d_leaves,
                   c->d_kinds, c->d_cvnodes, c->d_cvtrees, c->d_cvstages, c->d_tree_pass, c->d_tree_fail, c->d_tree_order,
-                  c->d_nodes_p16, c->d_nodes_sparse_p16, c->d_kinds_p16};
+                  c->d_nodes_p16, c->d_nodes_sparse_p16, c->d_kinds_p16, c->d_stages_seg, c->d_kinds_seg};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   c->d_tree_pass = c->d_tree_fail = c->d_tree_order = nullptr;
+  c->d_stages_seg = nullptr; c->d_kinds_seg = nullptr; c->cv_seg = false;
   c->d_nodes_p16 = c->d_nodes_sparse_p16 = nullptr; c->d_kinds_p16 = nullptr; c->p16 = false; c->spec_id_p16 = 0;
   c->d_nodes[0] = c->d_nodes[1] = c->d_nodes_sparse[0] = c->d_nodes_sparse[1] = nullptr;
   c->d_stages = nullptr; c->d_trees = nullptr; c->d_leaves = nullptr; c->d_kinds = nullptr;
@@ -406,6 +407,55 @@ int upload_model(hc_context* c) {
       int rc0 = hc::cv24_tree_tables(m, cn, ct, cs);
       if (rc0 != HC_OK) return rc0;
       if ((rc0 = dev_upload(&c->d_cvnodes, cn)) || (rc0 = dev_upload(&c->d_cvtrees, ct)) || (rc0 = dev_upload(&c->d_cvstages, cs))) return rc0;
+      // A stage tree of the form "a spine, then up to four chains tried one after the other" (haarcascade_frontalface_alt_tree:
+      // stages 0-4, then 5 -> 7 -> .. -> 39 and 6 -> 8 -> .. -> 46) runs on the chain kernel itself, segment after
+      // segment (cascade_body.inc "alternative chains"): the stage tables once more in evaluation order.
+      c->cv_seg = false;
+      if (m.is_stump() && c->k.cv24_seg) {
+        std::vector<int> order, heads;
+        bool ok = !cs.empty() && cs[0].parent < 0 && cs[0].next < 0;
+        for (int sidx = 0; ok;) {
+          order.push_back(sidx);
+          const int ch = cs[sidx].child;
+          if (ch < 0) { ok = false; break; }                        // a plain chain (cv24_is_chain would have said so)
+          if (cs[ch].next >= 0) {                                   // the branch point: the children of the spine's last stage
+            for (int h = ch; h >= 0; h = cs[h].next) heads.push_back(h);
+            break;
+          }
+          sidx = ch;
+        }
+        const int spine_len = (int)order.size();
+        int seg_end[4] = {0, 0, 0, 0};
+        ok = ok && !heads.empty() && heads.size() <= 4 && spine_len >= std::max(2, c->k.row_stages);
+        for (size_t g = 0; ok && g < heads.size(); g++) {
+          for (int t = heads[g]; t >= 0;) {
+            order.push_back(t);
+            const int ch = cs[t].child;
+            if (ch >= 0 && cs[ch].next >= 0) { ok = false; break; }   // a branch inside a chain: the general sweep takes it
+            t = ch;
+          }
+          seg_end[g] = (int)order.size();
+        }
+        std::vector<char> seen(cs.size(), 0);
+        for (int v : order) { if (v < 0 || v >= (int)cs.size() || seen[v]) ok = false; else seen[v] = 1; }
+        ok = ok && order.size() == cs.size() && order.size() < 64;   // (6 bits of a list entry count the stages passed)
+        if (ok) {
+          std::vector<hc::DevStage> sst(order.size());
+          std::vector<hc::DevStageKinds> skd(order.size());
+          for (size_t i = 0; i < order.size(); i++) { sst[i] = st[order[i]]; skd[i] = kinds[order[i]]; }
+          for (int i = (int)sst.size() - 1, all = 1; i >= 0; i--) {   // exact == 2: this stage and every later one IN THIS ORDER
+            if (sst[i].exact) sst[i].exact = 1;
+            all = all && sst[i].exact;
+            if (all) sst[i].exact = 2;
+          }
+          if ((rc0 = dev_upload(&c->d_stages_seg, sst)) || (rc0 = dev_upload(&c->d_kinds_seg, skd))) return rc0;
+          c->cv_seg = true;
+          for (int k = 0; k < 2; k++) c->lds_bytes[k] += (size_t)c->k.band_rows[k] * hc::TILE_POS * 2;   // the retry list, behind the tile
+          c->seg_n = (int)heads.size();
+          c->seg_spine = spine_len;
+          for (int g = 0; g < 4; g++) c->seg_end[g] = seg_end[g];
+        }
+      }
       // the same tree for the tiled kernel (stump cascades): per stage where a window goes when it passes (first child,
       // or accepted) and when it fails (next sibling of the nearest ancestor-or-self that has one, or rejected)
       c->cv_tree_tiled = m.is_stump() && cs.size() <= 250;

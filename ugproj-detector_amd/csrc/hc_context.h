@@ -65,6 +65,7 @@ struct Knobs {
   int strip_comp_max = 0;        // HC_STRIP_COMP_MAX: pixel columns a strip computes at most; 0: the widest that fits (tests: small values
                                  // cut small frames into several strips)
   bool cv24_fused = true;        // HC_CV24_FUSED=0: 2.4 semantics always through the four separate prep kernels
+  bool cv24_seg = true;          // HC_CV24_SEG=0: a 2.4 stage tree always through the preorder sweep (k_cv24_tree), never as alternative chains
   bool share_vnf = true;         // HC_SHARE_VNF=0: every member of a shared pass computes its own variance factors
   // ---- small-batch routes, streams, host
   int side_max_batch = 8;        // HC_SIDE_MAX_BATCH: up to this many 720p equivalents the two cascade launches run side by side
@@ -147,6 +148,11 @@ struct hc_context {
   hc::Cv24Stage* d_cvstages = nullptr;
   uint8_t *d_tree_pass = nullptr, *d_tree_fail = nullptr, *d_tree_order = nullptr;   // stage tree on the tiles (k_cv24_tree)
   bool cv_tree_tiled = false;
+  // stage tree as alternative chains on the chain kernel (api_model.cpp, cascade_body.inc): stage tables in evaluation order
+  bool cv_seg = false;
+  int seg_n = 0, seg_spine = 0, seg_end[4] = {0, 0, 0, 0};
+  hc::DevStage* d_stages_seg = nullptr;
+  hc::DevStageKinds* d_kinds_seg = nullptr;
   // several cascades over the same frames (hc_context_configure_shared): the leader owns the pyramid integrals of
   // the union ladder, followers read them.  prep_seq counts the leader's enqueues; a follower scans each once.
   hc_context* leader = nullptr;

@@ -43,6 +43,11 @@ struct CascadeArgs {
   int spec;                   // >= 1: id of the compiled early stages matching this cascade (spec_lookup), 0: none
   int frame_chunk;            // > 0: the grid is walked in chunks of this many frames (a multiple of 8), every band of a chunk
                               //   before the next chunk, so neighbouring bands of a frame stay close in time whatever the batch
+  // OpenCV-2.4 stage tree as alternative chains (casc_cv24 build; 0 segments: a plain chain of nstages stages).  The stage
+  // tables are laid out [spine, chain 1 | chain 2 | ..]; segment g covers device stages [seg_end[g - 1], seg_end[g]) and
+  // segment 0 holds the spine (its first spine_len stages: a failure there rejects) and the first chain.
+  int nseg, spine_len;
+  int seg_end[4];
 };
 
 // Compiled early stages of one known cascade (csrc/spec/spec_<tag>.hip): what the generic launcher needs to know.
@@ -59,7 +64,13 @@ int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, boo
 // adds a unit that was not linked into the library (hc_spec_plugin_load); the object must outlive the process' use of it
 int spec_register(const SpecUnit* u);
 // layout check between the library and a plug-in built from another checkout of these sources
-constexpr int SPEC_PLUGIN_ABI = 5 * 100000 + (int)sizeof(CascadeArgs) * 100 + (int)sizeof(DevStage);
+// (a plug-in carries the kernel TEXT of its checkout: besides the struct sizes, HC_KERNEL_LAYOUT names the version of everything
+// the text assumes without a struct saying so -- LDS layout of k_cascade, node-word encodings, TileGeom meaning, the 16-bit
+// tile's tables.  Bump it with any such change in cascade_body.inc / spec_unit.inc / api_model.cpp's table builders.)
+constexpr int HC_KERNEL_LAYOUT = 7;
+constexpr int SPEC_PLUGIN_ABI = (HC_KERNEL_LAYOUT * 1000 + (int)sizeof(CascadeArgs)) * 4096 +
+                                (((int)sizeof(DevStage) * 31 + (int)sizeof(DevNode)) * 31 + (int)sizeof(TileGeom)) * 31 + (int)sizeof(DevTree) +
+                                (int)sizeof(DevStageKinds) * 7 + (int)sizeof(DevLevel);
 
 // k_pyramid_integral: the context's knobs that reach the launcher, and what a launch then did (hc_context_last_launch)
 struct PrepKnobs { int frame_chunk = 32; bool var_ring = true, var_xring = true, var_split = true; int strip_comp_max = 0; };
