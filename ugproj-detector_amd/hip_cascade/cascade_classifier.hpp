@@ -20,6 +20,7 @@
 // no CPU fallback to hide behind.
 #pragma once
 
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -132,9 +133,20 @@ class CascadeClassifier {
                                                   flags, minSize.width, minSize.height, maxSize.width, maxSize.height,
                                                   reinterpret_cast<hc_rect*>(objects.data()), (int)objects.size(), &n);
     if (rc == HC_ERR_CAPACITY) {
-      // more rectangles than the first buffer holds: the detection is done, the library kept them (*out_count = how many)
+      // more rectangles than the first buffer holds: the detection is done, the library kept them for this thread
+      // (*out_count = how many).  Should they be gone all the same (HC_ERR_STATE), the call simply runs again with a
+      // buffer of the size it asked for -- a std::vector grows as needed, the caller never sizes it.
       objects.resize(n);
       rc = hc_detect_multiscale_reread(h_, reinterpret_cast<hc_rect*>(objects.data()), n, &n);
+      for (int attempt = 0; (rc == HC_ERR_STATE || rc == HC_ERR_CAPACITY) && attempt < 3; attempt++) {
+        objects.resize((size_t)std::max(n, (int)objects.size()) + 256);
+        rc = legacy_ ? hc_detect_multiscale_cv24(h_, data, mat_rows(image), mat_cols(image), step, scaleFactor, minNeighbors, flags,
+                                                minSize.width, minSize.height, maxSize.width, maxSize.height,
+                                                reinterpret_cast<hc_rect*>(objects.data()), (int)objects.size(), &n)
+                    : hc_detect_multiscale_image(h_, data, mat_rows(image), mat_cols(image), nch, step, scaleFactor, minNeighbors,
+                                                 flags, minSize.width, minSize.height, maxSize.width, maxSize.height,
+                                                 reinterpret_cast<hc_rect*>(objects.data()), (int)objects.size(), &n);
+      }
     }
     if (rc != HC_OK) {
       objects.clear();

@@ -10,6 +10,8 @@
 //       std::vector<cv::Rect>& rects)   [appends]              std::vector<Rect>& rects)   [appends]
 #pragma once
 
+#include <algorithm>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -35,14 +37,21 @@ class FaceDetector {
     if (!mat_is_u8c3(frame) || !mat_data(frame))
       throw std::invalid_argument("hip_cascade::FaceDetector::detectFaces: 8-bit 3-channel BGR frame required");
     int lower[3], upper[3];
-    for (int k = 0; k < 3; k++) { lower[k] = (int)cfg_.skin_lower[k]; upper[k] = (int)cfg_.skin_upper[k]; }
+    // cv::inRange on 8-bit data converts its scalar bounds to integers by ROUNDING (half to even), not by truncation: a
+    // configured 133.7 is 134 (identical for the reference's integer defaults, src/structure.cc:75-82)
+    for (int k = 0; k < 3; k++) { lower[k] = (int)std::nearbyint(cfg_.skin_lower[k]); upper[k] = (int)std::nearbyint(cfg_.skin_upper[k]); }
     std::vector<hc_rect> buf(1024);
     int n = 0;
     int rc = hc_detect_faces(cascade.handle(), mat_data(frame), mat_rows(frame), mat_cols(frame), mat_step(frame), lower, upper,
                              cfg_.scale, buf.data(), (int)buf.size(), &n);
-    if (rc == HC_ERR_CAPACITY) {                  // the library kept the rectangles: no second detection
+    if (rc == HC_ERR_CAPACITY) {                  // the library kept the rectangles for this thread: no second detection
       buf.resize(n);
       rc = hc_detect_multiscale_reread(cascade.handle(), buf.data(), n, &n);
+      for (int attempt = 0; (rc == HC_ERR_STATE || rc == HC_ERR_CAPACITY) && attempt < 3; attempt++) {   // gone all the same: run again, larger
+        buf.resize((size_t)std::max(n, (int)buf.size()) + 256);
+        rc = hc_detect_faces(cascade.handle(), mat_data(frame), mat_rows(frame), mat_cols(frame), mat_step(frame), lower, upper,
+                             cfg_.scale, buf.data(), (int)buf.size(), &n);
+      }
     }
     if (rc != HC_OK) throw std::runtime_error(std::string("hip_cascade::FaceDetector::detectFaces: ") + hc_last_error());
     for (int i = 0; i < n; i++) {
