@@ -8,6 +8,7 @@
 #   phase.txt             share of wave time per k_cascade phase (HC_PHASE build, if ugproj-detector_amd/libhip_cascade_PH.so exists)
 #   kernel_stats.csv      rocprofv3 --kernel-trace --stats of the default command
 #   pmc_*                 separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ+LDS counters), no tracing mixed in
+#   lds.json              LDS-array / bank-conflict / VALU shares of k_cascade from those counters (bench.py roofline.lds)
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/round
 rm -rf $O; mkdir -p $O
@@ -30,9 +31,10 @@ ARGS="$R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --no-timing-events --no-ex
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_fetch -- python3 $ARGS > $O/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_write -- python3 $ARGS > $O/pmc_write.log 2>&1 || exit 1
 echo "traffic passes done" >> $O/progress.txt
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq1 -- python3 $ARGS > $O/pmc_sq1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq1 -- python3 $ARGS > $O/pmc_sq1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq2 -- python3 $ARGS > $O/pmc_sq2.log 2>&1 || exit 1
 python3 $R/tools/pmc_summary.py $O > $O/pmc_summary.txt
+python3 $R/tools/lds_from_pmc.py $O/pmc_summary.txt $O/lds.json > /dev/null    # roofline.lds of bench.py reads profiles/rNN_lds.json
 FRAMES=$(python3 -c "import json; print(json.loads(open('$O/bench.json').read().strip().splitlines()[-1])['config']['frames_per_gpu_per_step'])")
 python3 $R/tools/traffic_from_pmc.py $O $O/traffic.json $FRAMES > /dev/null
 rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2    # raw csv are large; the summaries stay
