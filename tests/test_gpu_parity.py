@@ -1045,11 +1045,14 @@ def test_retrained_cascade_runs_its_plugin_stages(pkg, oracle, synth):
     assert np.array_equal(pkg.Cascade(hcc).detect_multiscale(frames[0], 1.1, 2, 0, (30, 30)), wantb[0])
 
 
-def test_p16_build_and_standard_build_agree(pkg, oracle, synth, monkeypatch):
-    """haarcascade_frontalface_alt qualifies for the 16-bit-tile build of the scan-step-1 launch (two windows per lane in
-    the row-form stages, rects of more than 257 pixels cut in two): 20 frames of 720p, all families, as whole bands --
-    stage taps of every level of three frames, raw candidates and boxes of all, with the build on (default) and off."""
-    path = oracle.cascade_path("alt")
+@pytest.mark.parametrize("name", ["alt", "default", "alt_tree"])
+def test_p16_build_and_standard_build_agree(pkg, oracle, synth, monkeypatch, name):
+    """The stump cascades qualify for the 16-bit-tile build of the scan-step-1 launch (two windows per lane in the row-form
+    stages; every rect sum formed modulo 2^16 is of a rect of at most 257 pixels: larger rects 0 are cut in two -- alt --,
+    complemented by rect 1's side strips or, in checkerboard stumps, replaced by their quadrants -- default's 24 x 24 window,
+    alt_tree): 20 frames of 720p, all families, as whole bands -- stage taps of every level of three frames, raw candidates and
+    boxes of all, with the build on (default) and off."""
+    path = oracle.cascade_path(name)
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     kinds = ["planted", "texture", "noise"]
     frames = np.stack([synth.make_frames(kinds[i % 3], 1, 720, 1280, first=700 + i)[0] for i in range(20)])

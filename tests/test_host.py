@@ -287,18 +287,21 @@ def test_compiled_stages_belong_to_exactly_their_cascade(pkg, oracle, tmp_path):
         subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag, str(nst), str(out)],
                               stdout=subprocess.DEVNULL)
         assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag
-    # the unit of the 16-bit-tile build (alt, scan step 1) comes from the same generator with --p16
-    inc = os.path.join(root, "ugproj-detector_amd", "csrc", "spec", "spec_altp.inc")
-    text = open(inc).read()
-    assert "0x%016xull" % hashes["alt"] in text and "p16 = true" in text
-    out = tmp_path / "spec_altp.inc"
-    subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path("alt"), "altp",
-                           re.search(r"nstages = (\d+)", text).group(1), str(out), "--p16"], stdout=subprocess.DEVNULL)
-    assert out.read_text() == text, "csrc/spec/spec_altp.inc is stale: run make -C ugproj-detector_amd specs"
-    # a cascade with a rect of more than 257 pixels in a compiled stage cannot take that build
-    r = subprocess.run(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path("default"), "x", "6", str(tmp_path / "x.inc"),
+    # the units of the 16-bit-tile build (scan step 1) come from the same generator with --p16: alt; default, whose 24 x 24 window
+    # has rects of up to 576 pixels in its compiled stages (cut in two, complemented by rect 1's side strips, or -- checkerboard
+    # stumps -- replaced by their quadrants, so that every rect sum formed is of at most 257 pixels); alt_tree
+    for name, tag in (("alt", "altp"), ("default", "dfltp"), ("alt_tree", "atreep")):
+        inc = os.path.join(root, "ugproj-detector_amd", "csrc", "spec", "spec_%s.inc" % tag)
+        text = open(inc).read()
+        assert "0x%016xull" % hashes[name] in text and "p16 = true" in text
+        out = tmp_path / ("spec_%s.inc" % tag)
+        subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag,
+                               re.search(r"nstages = (\d+)", text).group(1), str(out), "--p16"], stdout=subprocess.DEVNULL)
+        assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag
+    # a tree cascade cannot take that build
+    r = subprocess.run(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path("alt2"), "x", "6", str(tmp_path / "x.inc"),
                         "--p16"], capture_output=True, text=True)
-    assert r.returncode != 0 and "257" in (r.stderr + r.stdout)
+    assert r.returncode != 0 and "stump" in (r.stderr + r.stdout)
 
 
 def test_cpp_synthetic_frames_equal_the_python_generator(pkg, synth, tmp_path):

@@ -17,7 +17,8 @@ usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 ba
 --p16: the unit of the 16-bit-tile build of the kernel (cascade_body.inc HC_P16; scan step 1 only): corner offsets in
 2-byte entries, rect sums modulo 2^16, and for the row-form stages 0-1 a PAIR form that evaluates two adjacent windows per
 lane from 4-byte reads of entry pairs (even corner columns from copy A of the tile, odd ones from the shifted copy B).
-Refused when a rect of a compiled stage has more than 257 pixels.
+A rect 0 of more than 257 pixels is cut in two (two-rect stumps) or replaced by its checkerboard quadrants (three-rect stumps);
+refused when a compiled stage has a large rect of any other shape.
 """
 import math
 import struct
@@ -147,38 +148,80 @@ def emit_p16(L, m, nodes, first, nst, pitch, tree_terms, dwords, order):
         return (dy * pitch + dx) * 2
 
     def rects(n):
-        out = []
-        for r in range(3):
-            x, y, w, h = [int(v) for v in n["r"][r]]
-            wt = int(n["w"][r])
-            if r == 2 and wt == 0:
-                continue
-            out.append((wt, [(x, y), (x + w, y), (x, y + h), (x + w, y + h)]))
-        return out
+        """(coefficient, corners) of the feature value f = sum coefficient * rect sum, every rect of at most 257 pixels so that
+        its sum modulo 2^16 is its sum.  Rect 0 (weight -1) of more than 257 pixels: in a two-rect stump it is cut in two
+        halves (the same cut as api_model.cpp p16_model); in a three-rect stump it must be the 2 x 2 grid of a checkerboard
+        feature -- rects 1 and 2 two diagonal quadrants with weight 2 -- and 2 (S1 + S2) - S0 = S1 + S2 - S3 - S4 with the
+        other two quadrants S3, S4 (device: the checker form of cascade_body.inc)."""
+        R = [(int(n["w"][r]), [int(v) for v in n["r"][r]]) for r in range(3) if not (r == 2 and int(n["w"][2]) == 0)]
+        big = [i for i, (_, (x, y, w, h)) in enumerate(R) if w * h > 257]
+        if not big:
+            out = R
+        elif big != [0] or R[0][0] != -1:
+            raise SystemExit("--p16: a rect of more than 257 pixels that is not rect 0 with weight -1")
+        elif len(R) == 2:
+            x, y, w, h = R[0][1]
+            if h >= w:
+                h1 = h // 2
+                out = [(-1, [x, y, w, h1]), (-1, [x, y + h1, w, h - h1]), R[1]]
+            else:
+                w1 = w // 2
+                out = [(-1, [x, y, w1, h]), (-1, [x + w1, y, w - w1, h]), R[1]]
+            if max(r[2] * r[3] for _, r in out) > 257:
+                # halves still too large (24 x 24 windows: rect 0 of up to 576 pixels).  Rect 1 spans rect 0's full height or
+                # width: w1 S1 - S0 = (w1 - 1) S1 - (the one or two strips of rect 0 beside rect 1)
+                wt, (x1, y1, w1, h1) = R[1]
+                if (y1, h1) == (y, h) and x <= x1 and x1 + w1 <= x + w:
+                    strips = [[x, y, x1 - x, h], [x1 + w1, y, x + w - x1 - w1, h]]
+                elif (x1, w1) == (x, w) and y <= y1 and y1 + h1 <= y + h:
+                    strips = [[x, y, w, y1 - y], [x, y1 + h1, w, y + h - y1 - h1]]
+                else:
+                    raise SystemExit("--p16: a two-rect stump whose rect 0 neither halves nor complements into rects of <= 257 pixels")
+                out = [(-1, st) for st in strips if st[2] * st[3] > 0] + [(wt - 1, [x1, y1, w1, h1])]
+        else:
+            (x, y, w, h), (x1, y1, w1, h1), (x2, y2, w2, h2) = R[0][1], R[1][1], R[2][1]
+            if R[1][0] != 2 or R[2][0] != 2:
+                raise SystemExit("--p16: three-rect stump with a large rect 0 and weights other than (-1, 2, 2)")
+            if (x1, y1) == (x, y) and (x2 + w2, y2 + h2) == (x + w, y + h) and (x1 + w1, y1 + h1) == (x2, y2):      # diagonal
+                xm, ym = x2, y2
+                out = [(1, R[1][1]), (1, R[2][1]), (-1, [xm, y, x + w - xm, ym - y]), (-1, [x, ym, xm - x, y + h - ym])]
+            elif (x1 + w1, y1) == (x + w, y) and (x2, y2 + h2) == (x, y + h) and (x1, y1 + h1) == (x2 + w2, y2):    # anti-diagonal
+                xm, ym = x1, y1 + h1
+                out = [(1, R[1][1]), (1, R[2][1]), (-1, [x, y, xm - x, ym - y]), (-1, [xm, ym, x + w - xm, y + h - ym])]
+            else:
+                raise SystemExit("--p16: three-rect stump with a large rect 0 that is not a checkerboard")
+            if sum(r[2] * r[3] for _, r in out) != w * h:
+                raise SystemExit("--p16: checkerboard quadrants do not tile rect 0")
+        for _, (x, y, w, h) in out:
+            if w * h > 257 or w <= 0 or h <= 0:
+                raise SystemExit("--p16: a rect of more than 257 pixels remains")
+        return [(c, [(x, y), (x + w, y), (x, y + h), (x + w, y + h)]) for c, (x, y, w, h) in out]
+
+    def combine(terms):
+        """terms: (coefficient, C expression of a rect sum) -> the feature value as a C expression"""
+        pos = [e if c == 1 else "__mul24(%d, %s)" % (c, e) for c, e in terms if c > 0]
+        neg = [e if c == -1 else "__mul24(%d, %s)" % (-c, e) for c, e in terms if c < 0]
+        return (" + ".join(pos) if pos else "0") + "".join(" - " + e for e in neg)
 
     def feature1(n, corner):
         terms = []
-        for r, (wt, cs) in enumerate(rects(n)):
+        for coef, cs in rects(n):
             c = [corner.setdefault(off(dx, dy), "c%d" % len(corner)) for dx, dy in cs]
-            rs = "((%s - %s - %s + %s) & 0xffff)" % tuple(c)
-            terms.append(rs if r == 0 else "__mul24(%d, %s)" % (wt, rs))
-        return " + ".join(terms[1:]) + " - " + terms[0]
+            terms.append((coef, "((%s - %s - %s + %s) & 0xffff)" % tuple(c)))
+        return combine(terms)
 
     def feature2(n, corner, sums):
         """two windows: rect sums as hc_u16x2 (modulo 2^16 by construction), then one feature per window"""
         names = []
-        for r, (wt, cs) in enumerate(rects(n)):
+        for coef, cs in rects(n):
             c = []
             for dx, dy in cs:
                 key = ("A", off(dx, dy)) if dx % 2 == 0 else ("B", off(dx - 1, dy))
                 c.append(corner.setdefault(key, "p%d" % len(corner)))
             nm = "s%d" % len(sums)
             sums.append("const hc_u16x2 %s = %s - %s - %s + %s;" % ((nm,) + tuple(c)))
-            names.append((wt, nm))
-        def one(comp):
-            t = ["(int)%s.%s" % (nm, comp) if r == 0 else "__mul24(%d, (int)%s.%s)" % (wt, nm, comp) for r, (wt, nm) in enumerate(names)]
-            return " + ".join(t[1:]) + " - " + t[0]
-        return one("x"), one("y")
+            names.append((coef, nm))
+        return combine([(c, "(int)%s.x" % nm) for c, nm in names]), combine([(c, "(int)%s.y" % nm) for c, nm in names])
 
     for s in range(nst):
         thr = np.float32(np.float32(m["stages"]["thr"][s]) - np.float32(1e-5))
@@ -320,11 +363,6 @@ def main():
     if p16:
         if is_tree:
             raise SystemExit("--p16: stump cascades only")
-        for s in range(nst):
-            for k in range(nfirst[first[s]], nfirst[first[s + 1]]):
-                for r in range(3):
-                    if int(nodes[k]["w"][r]) != 0 and int(nodes[k]["r"][r][2]) * int(nodes[k]["r"][r][3]) > 257:
-                        raise SystemExit("--p16: stage %d has a rect of more than 257 pixels" % s)
         pitch16 = (geom(m["win_w"], m["win_h"], 1, band_rows[0])[0] + 1) & ~1
         L.append("  static constexpr int pitch1 = %d, pitch2 = 0;   // LDS tile row pitch in 2-byte entries (scan step 1 only)" % pitch16)
         L.append("  static constexpr bool p16 = true;")

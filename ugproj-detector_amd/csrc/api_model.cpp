@@ -202,9 +202,34 @@ void free_model_tables(hc_context* c) {
 // every corner offset of the 16-bit tile fits the 16-bit offset fields (trivially, for windows this build accepts)
 static bool node_kinds_fit_p16(const hc::Model& m) { return m.win_w <= 40 && m.win_h <= 40; }
 
-// The cascade with every rect of more than 257 pixels cut into two halves (same weight; the second half takes the
-// node's free third slot): rect sums modulo 2^16 are then exact for every rect, and the feature value -- an integer
-// expression, weights_are_small_integers -- is unchanged.  False when some node has no free slot or a half is still too big.
+// Checkerboard stump whose rect 0 -- the 2 x 2 grid -- has more than 257 pixels: rects 1 and 2 are two diagonal quadrants with
+// weight 2, so 2 (S1 + S2) - S0 = S1 + S2 - S3 - S4 with the other two quadrants, all four of at most 257 pixels, and all their
+// corners among the nine the stump reads anyway.  1: rects 1 / 2 are the top-left / bottom-right quadrants (NK_DIAG), 2: top-right
+// / bottom-left (NK_ANTIDIAG), 0: not of this form.  The device evaluates such a node in "checker form" (cascade_body.inc).
+static int p16_checker_form(const hc::ModelNode& n) {
+  if (n.weight[0] != -1.f || n.weight[1] != 2.f || n.weight[2] != 2.f) return 0;
+  const int kind = node_kind(n);
+  if (kind != hc::NK_DIAG && kind != hc::NK_ANTIDIAG) return 0;
+  const int x = n.rect[0][0], y = n.rect[0][1], w = n.rect[0][2], h = n.rect[0][3];
+  const int xm = kind == hc::NK_DIAG ? n.rect[2][0] : n.rect[1][0];
+  const int ym = kind == hc::NK_DIAG ? n.rect[2][1] : n.rect[1][1] + n.rect[1][3];
+  if (xm <= x || xm >= x + w || ym <= y || ym >= y + h) return 0;
+  const int qa[4] = {(xm - x) * (ym - y), (x + w - xm) * (ym - y), (xm - x) * (y + h - ym), (x + w - xm) * (y + h - ym)};
+  // rects 1 and 2 must BE those quadrants (node_kind only compares three corner pairs)
+  const int a1 = n.rect[1][2] * n.rect[1][3], a2 = n.rect[2][2] * n.rect[2][3];
+  if (kind == hc::NK_DIAG ? (a1 != qa[0] || a2 != qa[3]) : (a1 != qa[1] || a2 != qa[2])) return 0;
+  for (int q : qa) if (q > 257) return 0;
+  return kind == hc::NK_DIAG ? 1 : 2;
+}
+
+// The cascade re-expressed so that every rect sum the 16-bit tile forms is of a rect of at most 257 pixels (rect sums modulo
+// 2^16 are then exact); the feature value -- an integer expression, weights_are_small_integers -- is unchanged.  A rect 0
+// (weight -1) of more than 257 pixels
+//   - in a two-rect stump is cut into two halves, the second in the node's free third slot with the same weight; when the
+//     halves are still too large (24 x 24 windows: up to 576 pixels) and rect 1 spans rect 0's full height or width,
+//     w1 S1 - S0 = (w1 - 1) S1 - (the strips of rect 0 beside rect 1): rect 0 becomes one strip, rect 2 the other (weight -1);
+//   - in a three-rect stump must be a checkerboard's grid (p16_checker_form): the node stays as it is and is flagged.
+// False when some node fits none of these.
 static bool p16_model(const hc::Model& m, hc::Model& out) {
   out = m;
   for (hc::ModelNode& n : out.nodes) {
@@ -212,19 +237,38 @@ static bool p16_model(const hc::Model& m, hc::Model& out) {
     for (int r = 0; r < 3; r++)
       if (n.weight[r] != 0.f && n.rect[r][2] * n.rect[r][3] > 257) { if (big >= 0) return false; big = r; }
     if (big < 0) continue;
-    if (n.weight[2] != 0.f || big == 2) return false;
-    const int x = n.rect[big][0], y = n.rect[big][1], w = n.rect[big][2], h = n.rect[big][3];
-    if (h >= w) {
-      const int h1 = h / 2;
-      n.rect[big][3] = (int8_t)h1;
-      n.rect[2][0] = (int8_t)x; n.rect[2][1] = (int8_t)(y + h1); n.rect[2][2] = (int8_t)w; n.rect[2][3] = (int8_t)(h - h1);
-    } else {
-      const int w1 = w / 2;
-      n.rect[big][2] = (int8_t)w1;
-      n.rect[2][0] = (int8_t)(x + w1); n.rect[2][1] = (int8_t)y; n.rect[2][2] = (int8_t)(w - w1); n.rect[2][3] = (int8_t)h;
+    if (big != 0 || n.weight[0] != -1.f) return false;
+    if (n.weight[2] != 0.f) { if (p16_checker_form(n)) continue; return false; }
+    const int x = n.rect[0][0], y = n.rect[0][1], w = n.rect[0][2], h = n.rect[0][3];
+    const int hh = h / 2, wh = w / 2;
+    if (h >= w ? (w * hh <= 257 && w * (h - hh) <= 257) : (wh * h <= 257 && (w - wh) * h <= 257)) {
+      if (h >= w) {
+        n.rect[0][3] = (int8_t)hh;
+        n.rect[2][0] = (int8_t)x; n.rect[2][1] = (int8_t)(y + hh); n.rect[2][2] = (int8_t)w; n.rect[2][3] = (int8_t)(h - hh);
+      } else {
+        n.rect[0][2] = (int8_t)wh;
+        n.rect[2][0] = (int8_t)(x + wh); n.rect[2][1] = (int8_t)y; n.rect[2][2] = (int8_t)(w - wh); n.rect[2][3] = (int8_t)h;
+      }
+      n.weight[2] = -1.f;
+      continue;
     }
-    n.weight[2] = n.weight[big];
-    if (n.rect[big][2] * n.rect[big][3] > 257 || n.rect[2][2] * n.rect[2][3] > 257) return false;
+    // complement form
+    const int x1 = n.rect[1][0], y1 = n.rect[1][1], w1 = n.rect[1][2], h1 = n.rect[1][3];
+    int sa[4], sb[4];                       // the strips of rect 0 beside rect 1 (either may be empty)
+    if (y1 == y && h1 == h && x <= x1 && x1 + w1 <= x + w) {
+      sa[0] = x; sa[1] = y; sa[2] = x1 - x; sa[3] = h;
+      sb[0] = x1 + w1; sb[1] = y; sb[2] = x + w - x1 - w1; sb[3] = h;
+    } else if (x1 == x && w1 == w && y <= y1 && y1 + h1 <= y + h) {
+      sa[0] = x; sa[1] = y; sa[2] = w; sa[3] = y1 - y;
+      sb[0] = x; sb[1] = y1 + h1; sb[2] = w; sb[3] = y + h - y1 - h1;
+    } else {
+      return false;
+    }
+    if (sa[2] * sa[3] == 0) { for (int k = 0; k < 4; k++) { sa[k] = sb[k]; sb[k] = 0; } }
+    if (sa[2] * sa[3] == 0 || sa[2] * sa[3] > 257 || sb[2] * sb[3] > 257 || w1 * h1 > 257 || n.weight[1] - 1.f == 0.f) return false;
+    for (int k = 0; k < 4; k++) { n.rect[0][k] = (int8_t)sa[k]; n.rect[2][k] = (int8_t)sb[k]; }
+    n.weight[1] -= 1.f;
+    n.weight[2] = sb[2] * sb[3] ? -1.f : 0.f;
   }
   return true;
 }
@@ -234,6 +278,11 @@ static bool p16_model(const hc::Model& m, hc::Model& out) {
 static int upload_p16_tables(hc_context* c, const hc::Model& m16, const std::vector<hc::DevStage>& st) {
   std::vector<hc::DevNode> nd;
   build_nodes(m16, c->geom_p16, 1, nd, true);
+  // checker form: the node's unused w0 word (w0 == -1 is a premise of the integer build) carries 1 / 2 (p16_checker_form)
+  for (size_t i = 0; i < nd.size(); i++) {
+    const hc::ModelNode& mn = m16.nodes[i];
+    if (mn.weight[2] != 0.f && mn.rect[0][2] * mn.rect[0][3] > 257) nd[i].w[0] = (float)p16_checker_form(mn);
+  }
   std::vector<hc::DevStageKinds> kinds;
   for (size_t si = 0; si < m16.stages.size(); si++) {
     const hc::ModelStage& s = m16.stages[si];
@@ -525,9 +574,10 @@ int upload_model(hc_context* c) {
     if (id > 0 && p16_model(m, m16)) {
       hc::TileGeom g = make_geom(m, 1, prows);
       g.pitch = (g.cols + 1) & ~1;
-      const size_t tile_bytes = ((size_t)g.pitch * g.rows * 2 + 7) & ~(size_t)7;
-      const size_t fixed = (size_t)prows * hc::TILE_POS * (4 + 6 + 2) + 264;  // vnf | copy B (6 bytes per window; the list later) | bank matrix | 64 counters + ticket
-      if (tile_bytes <= (size_t)prows * hc::TILE_POS * 6 && node_kinds_fit_p16(m16)) {
+      const size_t tile_bytes = ((size_t)g.pitch * g.rows * 2 + 7) & ~(size_t)7;   // one copy (cascade_body.inc P16_COPY)
+      // vnf | copy B (the survivor list later) | bank matrix | 64 counters + ticket | copy A
+      const size_t fixed = (size_t)prows * hc::TILE_POS * (4 + 2) + 264 + tile_bytes;
+      if (tile_bytes >= (size_t)prows * hc::TILE_POS * 2 && node_kinds_fit_p16(m16)) {
         c->geom_p16 = g;
         c->tile_words_p16 = (int)(tile_bytes / 4);
         c->lds_bytes_p16 = fixed + tile_bytes;
