@@ -5,10 +5,10 @@ difference a scalar constant.  The generic kernel forms each corner address with
 node records by scalar loads; here a stump needs neither ("compiled early stages").
 
 The input is a cascade in the package's own HCC1 container (tools/pack_cascade.py; ugproj-detector_amd/data/cascades/*.hcc -- data, the
-same numbers as the XML).  The file records an FNV-1a hash of the model (hc_api.cpp model_hash walks the very same fields
+same numbers as the XML).  The file records an FNV-1a hash of the model (api_model.cpp model_hash walks the very same fields
 in the same order); the library takes the compiled stages only for a loaded cascade whose hash, window and tile
 geometry match, anything else runs the generic kernel.  Only stages whose f64 sum is exact in any order are compiled
-(same test as hc_api.cpp stage_sum_is_exact) and only integer-weight cascades (weights_are_small_integers).  Cascades
+(same test as api_model.cpp stage_sum_is_exact) and only integer-weight cascades (weights_are_small_integers).  Cascades
 of two-node trees (haarcascade_frontalface_alt2: a root, one of whose branches is a leaf) are compiled with both nodes of a
 tree evaluated and the leaf chosen by two selects.
 

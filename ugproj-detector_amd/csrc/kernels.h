@@ -52,7 +52,7 @@ struct CascadeArgs {
 
 // Compiled early stages of one known cascade (csrc/spec/spec_<tag>.hip): what the generic launcher needs to know.
 struct SpecUnit {
-  unsigned long long hash;   // hc_api.cpp model_hash of the cascade the unit was generated from
+  unsigned long long hash;   // api_model.cpp model_hash of the cascade the unit was generated from
   int win_w, win_h, nstages; // window; number of leading stages compiled
   bool tree;                 // the cascade has two nodes per tree (k_cascade's TREE instantiation)
   // 0 / hipError_t, or -1 when the unit has no kernel for this launch shape (the generic kernel runs then)

@@ -4,7 +4,7 @@
 // scalar C path, the cascade's stage tree honoured (data/haarcascade_frontalface_alt_tree.xml:1303-1304).
 // This file: the planning shared with the context code (scale loop, resize tables, hidden-cascade weights, stage tree)
 // and the two stand-alone entry points hc_plan_query_cv24 / hc_resize_linear_cv24.  The call itself runs through a
-// context like the OpenCV >= 4 semantics (hc_api.cpp, hc_context_set_semantics).  Parity unpinned (no OpenCV reachable).
+// context like the OpenCV >= 4 semantics (api_context.cpp, hc_context_set_semantics).  Parity unpinned (no OpenCV reachable).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>

@@ -1,5 +1,5 @@
 // legacy_cv24_host.h -- host-side planning of the OpenCV-2.4 ("T2") evaluation mode: scale loop,
-// resize coefficient tables, hidden-cascade weights and the stage tree, shared by the context code (hc_api.cpp) and the
+// resize coefficient tables, hidden-cascade weights and the stage tree, shared by the context code (api_model.cpp, api_context.cpp) and the
 // stand-alone entry points (legacy_cv24.cpp).
 #pragma once
 
