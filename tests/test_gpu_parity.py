@@ -895,6 +895,46 @@ def test_column_strips_on_small_frames(pkg, oracle, synth, monkeypatch, name, sh
         assert np.array_equal(got2[f], got[f]), (name, f)
 
 
+def test_strip_handoff_under_load(pkg, oracle, synth, monkeypatch):
+    """The strip-to-strip hand-off (plain sc1 stores of the carries, an sc1 row count, sc1 polls and loads on the other side; no
+    fences) with the chip oversubscribed and unevenly loaded: 24 noise frames of 1920x1080 in one batch with 256-column strips --
+    up to five strips per level, about 5,000 workgroups for 512 resident slots, neighbours on different XCDs, consumers that have
+    polled the same line many times.  EVERY word of both integrals of three multi-strip levels of EVERY frame against the oracle
+    (a stale or early carry shifts a whole strip of a row), then boxes of all frames."""
+    monkeypatch.setenv("HC_FUSED_PREP", "1")
+    monkeypatch.setenv("HC_STRIP_COMP_MAX", "256")
+    monkeypatch.setenv("HC_PI_FRAME_CHUNK", "8")
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 24
+    frames = np.stack([synth.make_frames("noise" if i % 2 else "texture", 1, 1080, 1920, first=5200 + i)[0] for i in range(B)])
+    ctx = pkg.Context(casc)
+    ctx.configure(1080, 1920, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 14)
+    ctx.enable_stage_taps(True)                        # the squares' integral and the pyramid exist in global memory only for a tap
+    got = ctx.detect_host(frames)
+    info = ctx.last_launch()
+    assert info["variance_route"] == "ring_strips" and info["pi_remapped"] == 1 and info["sq_stored"] == 1, info
+    levels = ctx.levels()
+    picks = [0, 3, 6]
+    assert all(levels[li].w > 600 for li in picks)      # three to five 256-column strips each
+    from concurrent.futures import ThreadPoolExecutor
+
+    def want(args):
+        f, li = args
+        L = levels[li]
+        return oracle.integral(oracle.resize_linear_exact(frames[f], L.h, L.w))
+    jobs = [(f, li) for f in range(B) for li in picks]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        wants = list(ex.map(want, jobs))
+    for (f, li), (ws, wq) in zip(jobs, wants):
+        assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_SUM), ws), (f, li)
+        assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_SQSUM), wq), (f, li)
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        boxes = list(ex.map(lambda fr: oc.detect(fr, 1.1, 2, (30, 30), (0, 0))[0], frames))
+    for f in range(B):
+        assert np.array_equal(got[f], boxes[f]), f
+
+
 @pytest.mark.parametrize("name", ["alt", "default", "alt_tree", "alt2"])
 @pytest.mark.parametrize("spec", ["1", "0"])
 def test_compiled_early_stages_and_generic_kernel_agree(pkg, oracle, synth, monkeypatch, name, spec):
