@@ -142,6 +142,9 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
     nraw = 0
     info = ctx.last_launch()
     assert info["prep_route"] == ("cv24_parallel" if route == "separate" else "cv24_fused"), info
+    # compiled early stages with the 2.4 node arithmetic (csrc/spec/spec_*24.hip) on the chain kernel -- chains of alt_tree
+    # included, whose first six stages keep their file order; the preorder sweep evaluates every stage generically
+    assert (ctx.compiled_stages() > 0) == (route != "fused_sweep"), (name, route, ctx.compiled_stages())
     assert info["variant"][0] == (("cv24_tree" if route == "fused_sweep" else "cv24_chains") if name == "alt_tree" else "cv24"), info
     # the f32 variance-factor tap of the >= 4 layout does not exist in this mode (f64 factors live in another buffer): the
     # read must fail cleanly instead of copying from a one-element stub
@@ -179,11 +182,13 @@ def test_cv24_batched_context(pkg, oracle, synth, name, route, monkeypatch):
         assert np.array_equal(got4[f], oc.detect(frames[f], 1.1, 2, (30, 30))[0]), (name, f)
 
 
-def test_cv24_fused_prep_720p_all_taps(pkg, oracle, synth, monkeypatch):
+@pytest.mark.parametrize("spec", ["1", "0"])
+def test_cv24_fused_prep_720p_all_taps(pkg, oracle, synth, monkeypatch, spec):
     """The fused 2.4 prep at the bench geometry: two 1280x720 frames, every level's stage taps (each depends on that window's
     f64 variance factor -- two levels have more than 512 grid columns, whose ring words live in LDS), the pyramid bytes and
     integrals of three levels, raw candidates and boxes."""
     monkeypatch.setenv("HC_FUSED_PREP", "1")
+    monkeypatch.setenv("HC_SPEC", spec)          # with the compiled 2.4 stages and with the generic kernel alone
     path = oracle.cascade_path("alt")
     casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
     frames = np.stack([synth.make_frames(k, 1, 720, 1280, first=620 + i)[0] for i, k in enumerate(["planted", "texture"])])
@@ -195,6 +200,7 @@ def test_cv24_fused_prep_720p_all_taps(pkg, oracle, synth, monkeypatch):
     ctx.enable_stage_taps(True)
     ctx.enable_timing(True)
     got = ctx.detect_host(frames)
+    assert (ctx.compiled_stages() > 0) == (spec == "1")
     ms = ctx.kernel_ms()
     assert ms["k_pyramid_integral"] > 0.05 and ms["k_integral_rows"] < 0.2 * ms["k_pyramid_integral"] and \
         ms["k_variance"] < 0.2 * ms["k_pyramid_integral"], ms

@@ -298,6 +298,15 @@ def test_compiled_stages_belong_to_exactly_their_cascade(pkg, oracle, tmp_path):
         subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag,
                                re.search(r"nstages = (\d+)", text).group(1), str(out), "--p16"], stdout=subprocess.DEVNULL)
         assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag
+    # ... and the units with OpenCV 2.4's node arithmetic with --cv24 (hidden f32 rect weights as immediates)
+    for name, tag in (("alt", "alt24"), ("alt2", "alt224"), ("default", "dflt24"), ("alt_tree", "atree24")):
+        inc = os.path.join(root, "ugproj-detector_amd", "csrc", "spec", "spec_%s.inc" % tag)
+        text = open(inc).read()
+        assert "0x%016xull" % hashes[name] in text and "cv24 = true" in text
+        out = tmp_path / ("spec_%s.inc" % tag)
+        subprocess.check_call(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path(name), tag,
+                               re.search(r"nstages = (\d+)", text).group(1), str(out), "--cv24"], stdout=subprocess.DEVNULL)
+        assert out.read_text() == text, "csrc/spec/spec_%s.inc is stale: run make -C ugproj-detector_amd specs" % tag
     # a tree cascade cannot take that build
     r = subprocess.run(["python3", os.path.join(root, "tools", "gen_spec.py"), oracle.cascade_path("alt2"), "x", "6", str(tmp_path / "x.inc"),
                         "--p16"], capture_output=True, text=True)

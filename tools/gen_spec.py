@@ -12,8 +12,11 @@ geometry match, anything else runs the generic kernel.  Only stages whose f64 su
 of two-node trees (haarcascade_frontalface_alt2: a root, one of whose branches is a leaf) are compiled with both nodes of a
 tree evaluated and the leaf chosen by two selects.
 
-usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 band_rows_ystep2] [--p16]
+usage: gen_spec.py <cascade.hcc> <tag> <n stages> <out.inc> [band_rows_ystep1 band_rows_ystep2] [--p16 | --cv24]
 
+--cv24: the stages with the node arithmetic of OpenCV 2.4 (cascade_body.inc HC_CV24, csrc/spec_unit_cv24.inc): hidden
+area-normalised f32 rect weights as immediates, value = (double)((float)S0 * w0) + (double)((float)S1 * w1) [+ ..], node test
+value < (double)thr * vnf with the f64 variance factor, stage bias 0.0001f.
 --p16: the unit of the 16-bit-tile build of the kernel (cascade_body.inc HC_P16; scan step 1 only): corner offsets in
 2-byte entries, rect sums modulo 2^16, and for the row-form stages 0-1 a PAIR form that evaluates two adjacent windows per
 lane from 4-byte reads of entry pairs (even corner columns from copy A of the tile, odd ones from the shifted copy B).
@@ -30,6 +33,7 @@ import os
 
 TILE_POS = 64
 GROUP = 2        # stumps whose corner reads are issued together
+CV24_GROUP = int(os.environ.get("HC_GEN_CV24_GROUP", "2"))   # ... in --cv24 units (f64 values and constants: twice the registers per stump)
 DUP_READS = int(os.environ.get("HC_GEN_DUP_READS", "0"))   # experiments only: never set when the committed files are generated
 
 
@@ -52,6 +56,10 @@ def load_hcc(path):
 
 def f32bits(x):
     return struct.unpack("<I", struct.pack("<f", float(x)))[0]
+
+
+def f32val(bits):
+    return struct.unpack("<f", struct.pack("<I", bits))[0]
 
 
 def model_hash(m):
@@ -290,8 +298,11 @@ def emit_p16(L, m, nodes, first, nst, pitch, tree_terms, dwords, order):
 
 
 def main():
-    argv = [a for a in sys.argv if a != "--p16"]
-    p16 = len(argv) != len(sys.argv)
+    argv = [a for a in sys.argv if a not in ("--p16", "--cv24")]
+    p16 = "--p16" in sys.argv
+    cv24 = "--cv24" in sys.argv          # OpenCV 2.4 node arithmetic (cascade_body.inc HC_CV24)
+    if p16 and cv24:
+        raise SystemExit("--p16 and --cv24 exclude each other")
     path, tag, nst, out = argv[1], argv[2], int(argv[3]), argv[4]
     band_rows = [int(argv[5]), int(argv[6])] if len(argv) > 6 else [16, 16]
     m = load_hcc(path)
@@ -354,12 +365,15 @@ def main():
         return bits & 0xffffffff, bits >> 32
     L = []
     L.append("// GENERATED by tools/gen_spec.py from %s -- do not edit.  Stages 0..%d of the cascade as straight-line code." % (path.split("/")[-1], nst - 1))
-    L.append("// Included inside namespace hc::casc_int by csrc/spec_unit.inc, after cascade_body.inc's helpers.")
+    L.append("// Included inside namespace hc::%s by csrc/%s, after cascade_body.inc's helpers." %
+             (("casc_cv24", "spec_unit_cv24.inc") if cv24 else ("casc_p16", "spec_unit_p16.inc") if p16 else ("casc_int", "spec_unit.inc")))
     L.append("struct Spec_%s {" % tag)
     L.append("  static constexpr unsigned long long hash = 0x%016xull;" % model_hash(m))
     L.append("  static constexpr int win_w = %d, win_h = %d, nstages = %d;" % (m["win_w"], m["win_h"], nst))
     L.append("  static constexpr bool is_tree = %s;   // two nodes per tree (the kernel's TREE instantiation)" % ("true" if is_tree else "false"))
     L.append("  static constexpr int band_rows1 = %d, band_rows2 = %d;" % (band_rows[0], band_rows[1]))
+    if cv24:
+        L.append("  static constexpr bool cv24 = true;   // 2.4 node arithmetic: hidden f32 rect weights, f64 value, value < thr * vnf (f64)")
     if p16:
         if is_tree:
             raise SystemExit("--p16: stump cascades only")
@@ -375,6 +389,7 @@ def main():
     L.append("  static constexpr int pitch1 = %d, pitch2 = %d;   // LDS tile row pitch (words) the offsets below assume" %
              (geom(m["win_w"], m["win_h"], 1, band_rows[0])[0], geom(m["win_w"], m["win_h"], 2, band_rows[1])[0]))
 
+    VNF_T, F_T = ("double", "double") if cv24 else ("float", "int")
     for ys in (1, 2):
         pitch, half, _ = geom(m["win_w"], m["win_h"], ys, band_rows[ys - 1])
 
@@ -382,24 +397,44 @@ def main():
             col = dx if ys == 1 else ((dx & 1) * half + (dx >> 1))
             return (dy * pitch + col) * 4
 
+        def hidden_weights(n):
+            """B.6, the operations of legacy_cv24.cpp cv24_weights in their types: w_k = (float)(weight_k * inv_area) for the rects
+            1 and 2 (f64 product), rect 0 balances them, w_0 = (float)(-sum_k (w_k * width_k * height_k) / area_0) with the
+            products formed in f32 and summed in f64"""
+            inv_area = 1.0 / float((m["win_w"] - 2) * (m["win_h"] - 2))
+            w = [np.float32(0), np.float32(0), np.float32(0)]
+            sum0 = 0.0
+            for k in (1, 2):
+                if float(n["w"][k]) == 0.0:
+                    continue
+                w[k] = np.float32(float(n["w"][k]) * inv_area)
+                sum0 += float(np.float32(np.float32(w[k] * np.float32(int(n["r"][k][2]))) * np.float32(int(n["r"][k][3]))))
+            w[0] = np.float32(-sum0 / float(int(n["r"][0][2]) * int(n["r"][0][3])))
+            return w
+
         def feature(n, corner):
             terms = []
+            hw = hidden_weights(n) if cv24 else None
             for r in range(3):
                 x, y, w, h = [int(v) for v in n["r"][r]]
                 wt = int(n["w"][r])
                 if r == 2 and wt == 0:
                     continue
                 c = [corner.setdefault(o, "c%d" % len(corner)) for o in (off(x, y), off(x + w, y), off(x, y + h), off(x + w, y + h))]
-                if r == 0:
+                if cv24:        # (double)((float)S_r * w_r), added in rect order
+                    terms.append("(double)((float)(%s - %s - %s + %s) * __uint_as_float(0x%08xu))" % (c[0], c[1], c[2], c[3], f32bits(hw[r])))
+                elif r == 0:
                     terms.append("(%s + %s - %s - %s)" % (c[1], c[2], c[0], c[3]))
                 else:
                     terms.append("__mul24(%d, %s - %s - %s + %s)" % (wt, c[0], c[1], c[2], c[3]))
+            if cv24:
+                return " + ".join(terms)
             return " + ".join(terms[1:] + terms[:1])
 
         for s in range(nst):
-            thr = np.float32(np.float32(m["stages"]["thr"][s]) - np.float32(1e-5))
+            thr = np.float32(np.float32(m["stages"]["thr"][s]) - np.float32(1e-4 if cv24 else 1e-5))   # B.8: stage bias 0.0001f
             bsum = sum(tree_terms(t)[0] for t in range(first[s], first[s + 1]))   # exact in f64 by stage_exact_terms
-            L.append("  static __device__ __forceinline__ bool stage%d_y%d(int a, float vnf) {" % (s, ys))
+            L.append("  static __device__ __forceinline__ bool stage%d_y%d(int a, %s vnf) {" % (s, ys, VNF_T))
             L.append("    double acc = %s;" % float(bsum).hex())
             if is_tree:
                 for t in range(first[s], first[s + 1]):                # one tree (two nodes) per read batch
@@ -410,17 +445,24 @@ def main():
                     L.append("    {")
                     L.append("      int l0, h0; K(l0, h0, 0x%08x, 0x%08x);" % dwords(d1))
                     L.append("      int l1, h1; K(l1, h1, 0x%08x, 0x%08x);" % dwords(d2))
+                    if cv24:
+                        L.append("      int tl0, th0; K(tl0, th0, 0x%08x, 0x%08x);" % dwords(float(np.float32(n0["thr"]))))
+                        L.append("      int tl1, th1; K(tl1, th1, 0x%08x, 0x%08x);" % dwords(float(np.float32(n1["thr"]))))
                     L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
                     L.append("      __builtin_amdgcn_sched_barrier(0);")
-                    L.append("      const int f0 = %s;" % f0)
-                    L.append("      const int f1 = %s;" % f1)
-                    L.append("      A2(acc, vnf, f0, 0x%08xu, f1, 0x%08xu, %s, l0, h0, l1, h1);" %
-                             (f32bits(n0["thr"]), f32bits(n1["thr"]), "true" if left_is_node else "false"))
+                    L.append("      const %s f0 = %s;" % (F_T, f0))
+                    L.append("      const %s f1 = %s;" % (F_T, f1))
+                    if cv24:
+                        L.append("      A2(acc, vnf, f0, tl0, th0, f1, tl1, th1, %s, l0, h0, l1, h1);" % ("true" if left_is_node else "false"))
+                    else:
+                        L.append("      A2(acc, vnf, f0, 0x%08xu, f1, 0x%08xu, %s, l0, h0, l1, h1);" %
+                                 (f32bits(n0["thr"]), f32bits(n1["thr"]), "true" if left_is_node else "false"))
                     L.append("    }")
             else:
                 ks = order_for_sharing(nodes, list(range(first[s], first[s + 1])))
-                for g0 in range(0, len(ks), GROUP):
-                    grp = ks[g0:g0 + GROUP]
+                grp_n = CV24_GROUP if cv24 else GROUP
+                for g0 in range(0, len(ks), grp_n):
+                    grp = ks[g0:g0 + grp_n]
                     corner = {}                      # byte offset -> local name (corners shared inside the group are read once)
                     feats, consts = [], []
                     for gi, k in enumerate(grp):
@@ -428,28 +470,33 @@ def main():
                         feats.append(feature(n, corner))
                         consts.append((f32bits(n["thr"]),) + dwords(tree_terms(k)[1][0]))
                     L.append("    {")
-                    for gi, (_, lo, hi) in enumerate(consts):
+                    for gi, (thrb, lo, hi) in enumerate(consts):
                         L.append("      int l%d, h%d; K(l%d, h%d, 0x%08x, 0x%08x);" % (gi, gi, gi, gi, lo, hi))
+                        if cv24:    # (double)thr as a 64-bit constant set where it is used (an f64 operand cannot be a literal)
+                            L.append("      int tl%d, th%d; K(tl%d, th%d, 0x%08x, 0x%08x);" % ((gi, gi, gi, gi) + dwords(float(f32val(thrb)))))
                     L.append("      const int " + ", ".join("%s = T(a, %d)" % (nm, o) for o, nm in corner.items()) + ";")
                     if s < DUP_READS:       # sensitivity probe (HC_GEN_DUP_READS): every corner of the first stages read twice
                         for o in corner:
                             L.append("      asm volatile(\"\" :: \"v\"(T(a, %d)));" % o)
                     L.append("      __builtin_amdgcn_sched_barrier(0);")
                     for gi, f in enumerate(feats):
-                        L.append("      const int f%d = %s;" % (gi, f))
+                        L.append("      const %s f%d = %s;" % (F_T, gi, f))
                     for gi, (thrb, _, _) in enumerate(consts):
-                        L.append("      A(acc, vnf, f%d, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
+                        if cv24:
+                            L.append("      A(acc, vnf, f%d, tl%d, th%d, l%d, h%d);" % (gi, gi, gi, gi, gi))
+                        else:
+                            L.append("      A(acc, vnf, f%d, 0x%08xu, l%d, h%d);" % (gi, thrb, gi, gi))
                     L.append("    }")
             L.append("    return !(acc < (double)__uint_as_float(0x%08xu));" % f32bits(thr))
             L.append("  }")
-        L.append("  static __device__ __forceinline__ bool eval_y%d(int s, int a, float vnf) {" % ys)
+        L.append("  static __device__ __forceinline__ bool eval_y%d(int s, int a, %s vnf) {" % (ys, VNF_T))
         L.append("    switch (s) {")
         for s in range(nst):
             L.append("      case %d: return stage%d_y%d(a, vnf);" % (s, s, ys))
         L.append("      default: return false;")
         L.append("    }")
         L.append("  }")
-    L.append("  template <int YS> static __device__ __forceinline__ bool eval(int s, int a, float vnf) {")
+    L.append("  template <int YS> static __device__ __forceinline__ bool eval(int s, int a, %s vnf) {" % VNF_T)
     L.append("    return YS == 1 ? eval_y1(s, a, vnf) : eval_y2(s, a, vnf);")
     L.append("  }")
     L.append("};")

@@ -277,13 +277,13 @@ int launch_cascades(hc_context* c, const Batch& b) {
       A.stages = c->d_stages_seg; A.kinds = c->d_kinds_seg;
       A.nseg = c->seg_n; A.spine_len = c->seg_spine;
       for (int g = 0; g < 4; g++) A.seg_end[g] = c->seg_end[g];
-      e = launch_cascade_cv24(ks, b.nframes, false, c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A);
+      e = launch_cascade_cv24(ks, b.nframes, false, c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A, &compiled);
       variant = HC_VARIANT_CV24_CHAINS;
     } else if (c->semantics == 1 && !c->cv_chain) {
       e = launch_cv24_tree(ks, b.nframes, c->k.band_waves[k], c->lds_bytes[k], A);
       variant = HC_VARIANT_CV24_TREE;
     } else if (c->semantics == 1) {
-      e = launch_cascade_cv24(ks, b.nframes, !m.is_stump(), c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A);
+      e = launch_cascade_cv24(ks, b.nframes, !m.is_stump(), c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A, &compiled);
       variant = HC_VARIANT_CV24;
     } else {
       e = launch_cascade(ks, b.nframes, !m.is_stump(), seg, c->k.band_rows[k], c->k.band_waves[k], p16 ? c->lds_bytes_p16 : c->lds_bytes[k],

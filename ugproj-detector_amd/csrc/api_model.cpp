@@ -447,6 +447,9 @@ int upload_model(hc_context* c) {
   for (const auto& pl : pair_left) tr[pl.first].pad = pl.second;
   c->int_weights = !cv24 && c->k.allow_int_weights && weights_are_small_integers(m);
   c->spec_id = c->int_weights && c->k.allow_spec ? hc::spec_lookup(model_hash(m), m.win_w, m.win_h, nullptr) : 0;
+  int cv24_spec_stages = 0;
+  if (cv24 && c->k.allow_spec)      // compiled early stages with the 2.4 node arithmetic (csrc/spec/spec_*24.hip)
+    c->spec_id = hc::spec_lookup(model_hash(m), m.win_w, m.win_h, &cv24_spec_stages, false, true);
   if (cv24) {
     c->cv_chain = hc::cv24_is_chain(m);
     if (!c->cv_chain) {           // a real stage tree: tables of the window-at-a-time kernel
@@ -488,6 +491,9 @@ int upload_model(hc_context* c) {
         std::vector<char> seen(cs.size(), 0);
         for (int v : order) { if (v < 0 || v >= (int)cs.size() || seen[v]) ok = false; else seen[v] = 1; }
         ok = ok && order.size() == cs.size() && order.size() < 64;   // (6 bits of a list entry count the stages passed)
+        // (compiled stages are generated in FILE order: a unit applies only while the evaluation order keeps it)
+        for (int i = 0; ok && i < cv24_spec_stages; i++)
+          if (order[i] != i) { c->spec_id = 0; break; }
         if (ok) {
           std::vector<hc::DevStage> sst(order.size());
           std::vector<hc::DevStageKinds> skd(order.size());
@@ -505,6 +511,7 @@ int upload_model(hc_context* c) {
           for (int g = 0; g < 4; g++) c->seg_end[g] = seg_end[g];
         }
       }
+      if (!c->cv_seg) c->spec_id = 0;     // the preorder sweep and the window-at-a-time kernel evaluate every stage generically
       // the same tree for the tiled kernel (stump cascades): per stage where a window goes when it passes (first child,
       // or accepted) and when it fails (next sibling of the nearest ancestor-or-self that has one, or rejected)
       c->cv_tree_tiled = m.is_stump() && cs.size() <= 250;

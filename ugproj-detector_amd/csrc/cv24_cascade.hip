@@ -132,9 +132,17 @@ int launch_cv24_tree(hipStream_t st, int nframes, int nwaves, size_t lds_bytes, 
 }
 
 // The production band shapes only: 16 grid rows, 4 wavefronts at scan step 1 and 8 at scan step 2, whole bands.
-int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args) {
+int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args, int* compiled) {
+  if (compiled) *compiled = 0;
   if (args.nbands == 0 || nframes == 0) return 0;
   if (rows != 16 || (nwaves != 4 && nwaves != 8)) return (int)hipErrorInvalidValue;
+  // compiled early stages with the 2.4 node arithmetic (csrc/spec/spec_*24.hip; args.spec from spec_lookup(.., cv24 = true))
+  if (const SpecUnit* unit = args.spec > 0 ? spec_unit(args.spec) : nullptr) {
+    if (unit->cv24 && unit->tree == tree) {
+      const int rc = unit->launch(st, nframes, false, rows, nwaves, lds_bytes, args);
+      if (rc >= 0) { if (compiled) *compiled = unit->nstages; return rc; }
+    }
+  }
   const dim3 grid(nframes, args.nbands), block(nwaves * 64);
 #define HC_GO(TREE, NW, TAPS) hipLaunchKernelGGL((casc_cv24::k_cascade<TREE, 16, NW, false, TAPS>), grid, block, lds_bytes, st, args)
   if (tree) {

@@ -311,7 +311,8 @@ int sync_context(hc_cascade* c, int rows, int cols, double scale_factor, int min
                  int max_h, hc_context** out, int semantics = 0);
 
 // ---- the 2.4 generation's launchers (cv24_cascade.hip)
-int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
+int launch_cascade_cv24(hipStream_t st, int nframes, bool tree, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args,
+                        int* compiled = nullptr);
 int launch_cv24_tree(hipStream_t st, int nframes, int nwaves, size_t lds_bytes, const CascadeArgs& args);
 int launch_cv24_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items, const uint32_t* sum,
                          const uint32_t* sq, size_t int_stride, int norm_w, int norm_h, double inv_area, double* vnf, size_t grid_stride);

@@ -58,9 +58,11 @@ struct SpecUnit {
   // 0 / hipError_t, or -1 when the unit has no kernel for this launch shape (the generic kernel runs then)
   int (*launch)(hipStream_t st, int nframes, bool segments, int rows, int nwaves, size_t lds_bytes, const CascadeArgs& args);
   bool p16;                  // unit of the 16-bit-tile build (cascade_body.inc HC_P16): scan step 1, whole bands, its own node tables
+  bool cv24 = false;         // unit of the OpenCV-2.4 build (cascade_body.inc HC_CV24): whole bands, the context's 2.4 tables
 };
 // id (>= 1) of the unit matching a model, 0 if none; *nstages (nullable) = stages it compiles
-int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16 = false);
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16 = false, bool cv24 = false);
+const SpecUnit* spec_unit(int id);   // the unit of an id returned by spec_lookup (null: none)
 // adds a unit that was not linked into the library (hc_spec_plugin_load); the object must outlive the process' use of it
 int spec_register(const SpecUnit* u);
 // layout check between the library and a plug-in built from another checkout of these sources

@@ -60,22 +60,24 @@ static const SpecUnit* spec_unit_by_id(int id) {   // 1-based
   return k >= 0 && k < (int)g_spec_extra.size() ? g_spec_extra[k] : nullptr;
 }
 
+const SpecUnit* spec_unit(int id) { return spec_unit_by_id(id); }
+
 int spec_register(const SpecUnit* u) {
   if (!u || !u->launch || u->nstages <= 0) return -1;
   std::lock_guard<std::mutex> l(g_spec_mu);
   for (const SpecUnit* e : g_spec_extra)
-    if (e->hash == u->hash && e->win_w == u->win_w && e->win_h == u->win_h && e->p16 == u->p16) return 0;     // already there
+    if (e->hash == u->hash && e->win_w == u->win_w && e->win_h == u->win_h && e->p16 == u->p16 && e->cv24 == u->cv24) return 0;   // already there
   g_spec_extra.push_back(u);
   return 0;
 }
 
-int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16) {
+int spec_lookup(unsigned long long hash, int win_w, int win_h, int* nstages, bool p16, bool cv24) {
   constexpr int nb = (int)(sizeof(spec_units) / sizeof(spec_units[0]));
   int nextra;
   { std::lock_guard<std::mutex> l(g_spec_mu); nextra = (int)g_spec_extra.size(); }
   for (int id = 1; id <= nb + nextra; id++) {
     const SpecUnit* u = spec_unit_by_id(id);
-    if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h && u->p16 == p16) {
+    if (u && u->hash == hash && u->win_w == win_w && u->win_h == win_h && u->p16 == p16 && u->cv24 == cv24) {
       if (nstages) *nstages = u->nstages;
       return id;
     }
