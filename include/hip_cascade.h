@@ -351,6 +351,15 @@ typedef struct hc_launch_info {
 } hc_launch_info;
 HC_API int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out);
 
+/* The column strips the fused prep kernel (k_pyramid_strips) would run for this call on a rows x cols image: pure host code, for
+ * the CPU tests of the planner.  strips[12 * i ..] = level, c0, c1, ce (stored pixel columns [c0, c1), computed [c0, ce)), g0, g1
+ * (grid columns whose variance factors the strip emits), sx0, sxn (staged source bytes of a row), left (index of the left neighbour,
+ * -1: none), has_right, carry_ofs, 0.  comp_max: pixel columns a strip computes at most, 0 = the library's choice (the widest of
+ * 832 / 640 / 512 / 384 that leaves two workgroups per CU).  *lds_bytes = LDS per workgroup, 0 when the geometry has no strip plan
+ * (*nstrips = 0 then).  semantics as hc_context_set_semantics. */
+HC_API int hc_debug_plan_strips(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w,
+                                int max_h, int semantics, int comp_max, int32_t* strips, int cap, int* nstrips, int64_t* lds_bytes);
+
 /* Device and pinned-host allocations the library has made in this process so far (hipMalloc / hipHostMalloc
  * calls): tests use it to show that a steady state allocates nothing. */
 HC_API long long hc_debug_alloc_count(void);

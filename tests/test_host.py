@@ -313,6 +313,52 @@ def test_compiled_stages_belong_to_exactly_their_cascade(pkg, oracle, tmp_path):
     assert r.returncode != 0 and "stump" in (r.stderr + r.stdout)
 
 
+@pytest.mark.parametrize("name,shape,comp", [("alt", (720, 1280), 0), ("default", (720, 1280), 0), ("alt2", (1080, 1920), 0),
+                                             ("default", (2160, 3840), 0), ("alt", (240, 320), 96), ("alt_tree", (203, 331), 64),
+                                             ("alt", (97, 131), 0), ("default", (1080, 1920), 256)])
+def test_strip_plan_invariants(pkg, oracle, name, shape, comp):
+    """The planner of the fused prep kernel's column strips (pure host code): the strips of a level tile its columns exactly and
+    left to right, every strip computes its own windows' halo, owns at most one register ring per thread, stages at most 2 KB of
+    a source row, and the whole workgroup fits two to a CU; the hand-off links and carry blocks are consistent."""
+    casc = pkg.Cascade(oracle.cascade_path(name))
+    levels, _ = casc.plan(shape[0], shape[1], 1.1, (30, 30))
+    strips, lds = casc.plan_strips(shape[0], shape[1], 1.1, (30, 30), comp_max=comp)
+    assert len(strips) >= len(levels) and 0 < lds <= 81920
+    nw = casc.win_w - 2
+    by_level = {}
+    for i, (lv, c0, c1, ce, g0, g1, sx0, sxn, left, has_right, carry_ofs, _z) in enumerate(strips.tolist()):
+        by_level.setdefault(lv, []).append(i)
+        L = levels[lv]
+        assert 0 <= c0 < c1 <= ce <= L.w
+        assert ce - c0 <= (comp if comp else 832) and g1 - g0 <= 512 and sxn <= 2048 and sx0 % 4 == 0 and sxn % 4 == 0
+        assert 0 <= g0 <= g1 <= L.nx
+        for g in range(g0, g1):                                # a window's inner-rect box sum lies inside the computed columns
+            assert c0 <= g * L.ystep and g * L.ystep + nw < ce
+        # the staged span holds both bilinear taps of every computed pixel (source x of dest x: (x + 0.5) cols / w - 0.5; one
+        # column of slack for the fixed-point coefficient rule)
+        first_tap = max(0, int(np.floor((c0 + 0.5) * shape[1] / L.w - 0.5)))
+        last_tap = min(shape[1] - 1, int(np.floor((ce - 1 + 0.5) * shape[1] / L.w - 0.5)) + 1)
+        assert sx0 <= first_tap + 1 and sx0 + sxn >= last_tap, (lv, c0, ce, sx0, sxn, first_tap, last_tap)
+    assert sorted(by_level) == list(range(len(levels)))        # widest levels first, every level present
+    carry_blocks = []
+    for lv, idx in by_level.items():
+        L = levels[lv]
+        assert idx == list(range(idx[0], idx[0] + len(idx)))   # strips of a level are contiguous, left to right
+        rows_ = strips[idx]
+        assert rows_[0, 1] == 0 and rows_[-1, 2] == L.w and all(rows_[k, 2] == rows_[k + 1, 1] for k in range(len(idx) - 1))
+        assert rows_[0, 4] == 0 and rows_[-1, 5] == L.nx and all(rows_[k, 5] == rows_[k + 1, 4] for k in range(len(idx) - 1))
+        for k, i in enumerate(idx):
+            assert strips[i, 8] == (idx[k - 1] if k else -1)    # left neighbour: the previous strip of the level (smaller index)
+            assert strips[i, 9] == (1 if k + 1 < len(idx) else 0)
+            if strips[i, 9]:
+                carry_blocks.append((int(strips[i, 10]), 2 * L.h))
+    carry_blocks.sort()
+    for (a, n), (b, _) in zip(carry_blocks, carry_blocks[1:]):
+        assert a % 2 == 0 and a + n <= b                        # 8-byte aligned, disjoint
+    if comp == 0 and shape == (720, 1280) and name == "alt":
+        assert sum(len(v) > 1 for v in by_level.values()) == 2  # only the two scan-step-1 levels with more than 512 grid columns are cut
+
+
 def test_cpp_synthetic_frames_equal_the_python_generator(pkg, synth, tmp_path):
     """SURVEY 8d asks for ONE deterministic generator in C++ and Python: hip_cascade/synth.hpp (what throughput_demo and
     multi_gpu_demo feed themselves with) writes the same bytes as synth.py for every family, ragged sizes included."""

@@ -92,6 +92,8 @@ _SIGS = {
     "hc_spec_plugin_load": (C.c_int, [C.c_char_p]),
     "hc_context_compiled_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "hc_context_last_launch": (C.c_int, [C.c_void_p, C.POINTER(LaunchInfo)]),
+    "hc_debug_plan_strips": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double] + [C.c_int] * 6 +
+                             [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "hc_cascade_dump": (C.c_int, [C.c_void_p] + [C.c_void_p] * 8),
     "hc_detect_multiscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -212,6 +214,15 @@ class Cascade:
         _check(lib.hc_plan_query(self._h, rows, cols, scale_factor, min_size[0], min_size[1], max_size[0],
                                  max_size[1], buf, 256, C.byref(n), C.byref(ab)))
         return [buf[i] for i in range(n.value)], ab.value
+
+    def plan_strips(self, rows, cols, scale_factor=1.1, min_size=(0, 0), max_size=(0, 0), cv24=False, comp_max=0):
+        """(strips, lds_bytes): the column strips of the fused prep kernel for this call (hc_debug_plan_strips); strips is an
+        (n, 12) int32 array: level, c0, c1, ce, g0, g1, sx0, sxn, left, has_right, carry_ofs, 0.  Pure host."""
+        buf = np.zeros((4096, 12), np.int32)
+        n, lds = C.c_int(), C.c_int64()
+        _check(lib.hc_debug_plan_strips(self._h, rows, cols, scale_factor, min_size[0], min_size[1], max_size[0], max_size[1],
+                                        1 if cv24 else 0, comp_max, buf.ctypes.data, len(buf), C.byref(n), C.byref(lds)))
+        return buf[:n.value].copy(), lds.value
 
     def plan_cv24(self, rows, cols, scale_factor=1.1, min_size=(0, 0), max_size=(0, 0)):
         """levels of the legacy (OpenCV 2.4) call: list of dicts factor, w, h, ystep, nx, ny, win_w, win_h; pure host"""

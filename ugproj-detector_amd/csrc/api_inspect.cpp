@@ -141,6 +141,33 @@ int hc_context_kernel_ms(hc_context* ctx, float ms[HC_NKERNELS]) {
   return HC_OK;
 }
 
+int hc_debug_plan_strips(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w, int max_h,
+                         int semantics, int comp_max, int32_t* strips, int cap, int* nstrips, int64_t* lds_bytes) {
+  if (!c || !nstrips) return hc::set_err(HC_ERR_ARG, "null argument");
+  *nstrips = 0;
+  if (lds_bytes) *lds_bytes = 0;
+  hc::Plan P;
+  hc::Cv24Host cv;
+  const int rc = semantics == 1 ? hc::build_plan_cv24(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, 16, 16, P, cv)
+                                : hc::build_plan(c->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, 16, 16, P);
+  if (rc != HC_OK) return hc::set_err(rc, "cannot plan this configuration");
+  if (P.levels.empty() || (semantics == 1 && !cv.fused_tables)) return HC_OK;
+  hc::PrepKnobs k;
+  k.strip_comp_max = comp_max;
+  hc::StripPlan sp;
+  hc::plan_pyramid_strips(P.levels, P.xtab, cols, c->model.win_w - 2, c->model.win_h - 2, semantics, k, sp);
+  if (!sp.ok) return HC_OK;
+  *nstrips = (int)sp.strips.size();
+  if (lds_bytes) *lds_bytes = (int64_t)sp.lds_bytes;
+  if ((int)sp.strips.size() > cap || !strips) return hc::set_err(HC_ERR_CAPACITY, "strip buffer too small");
+  for (size_t i = 0; i < sp.strips.size(); i++) {
+    const hc::DevStrip& T = sp.strips[i];
+    const int32_t v[12] = {T.level, T.c0, T.c1, T.ce, T.g0, T.g1, T.sx0, T.sxn, T.left, T.has_right, T.carry_ofs, 0};
+    for (int j = 0; j < 12; j++) strips[12 * i + j] = v[j];
+  }
+  return HC_OK;
+}
+
 int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out) {
   if (!ctx || !out) return hc::set_err(HC_ERR_ARG, "null argument");
   if (!ctx->configured) return hc::set_err(HC_ERR_STATE, "context not configured");
