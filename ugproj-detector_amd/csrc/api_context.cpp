@@ -20,6 +20,8 @@ Knobs knobs_from_env() {
   geti("HC_SPARSE_MAX", k.sparse_max, 0, 256);        // a wavefront owns at most 64 of them
   geti("HC_HOST_THREADS", k.host_threads, 1, 1 << 20);
   geti("HC_DEBUG_MAX_STAGES", k.debug_max_stages, 0, 1 << 20);
+  geti("HC_DEBUG_LDS_PAD1", k.debug_lds_pad[0], 0, 1 << 17);
+  geti("HC_DEBUG_LDS_PAD2", k.debug_lds_pad[1], 0, 1 << 17);
   geti("HC_ROW_STAGES", k.row_stages, 1, 1 << 20);
   if (const char* e = getenv("HC_BAND_ROWS1")) k.band_rows[0] = atoi(e);
   if (const char* e = getenv("HC_BAND_ROWS2")) k.band_rows[1] = atoi(e);

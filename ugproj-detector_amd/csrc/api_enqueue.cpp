@@ -286,8 +286,8 @@ int launch_cascades(hc_context* c, const Batch& b) {
       e = launch_cascade_cv24(ks, b.nframes, !m.is_stump(), c->k.band_rows[k], c->k.band_waves[k], c->lds_bytes[k], A, &compiled);
       variant = HC_VARIANT_CV24;
     } else {
-      e = launch_cascade(ks, b.nframes, !m.is_stump(), seg, c->k.band_rows[k], c->k.band_waves[k], p16 ? c->lds_bytes_p16 : c->lds_bytes[k],
-                         A, &compiled, &variant);
+      e = launch_cascade(ks, b.nframes, !m.is_stump(), seg, c->k.band_rows[k], c->k.band_waves[k],
+                         (p16 ? c->lds_bytes_p16 : c->lds_bytes[k]) + (size_t)c->k.debug_lds_pad[k], A, &compiled, &variant);
     }
     if (e) return hip_fail("k_cascade", e);
     if (A.nbands > 0) {

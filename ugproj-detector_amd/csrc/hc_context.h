@@ -52,6 +52,7 @@ struct Knobs {
   bool pair_form = true;         // HC_PAIR_FORM=0: tree stages always walk their trees per lane (A/B, debugging)
   bool allow_p16 = true;         // HC_P16=0: never the 16-bit-tile build
   int debug_max_stages = 0;      // HC_DEBUG_MAX_STAGES: truncate the cascade (wrong results; kernel-time experiments only)
+  int debug_lds_pad[2] = {0, 0}; // HC_DEBUG_LDS_PAD1/2: extra LDS bytes per cascade workgroup (occupancy experiments only)
   // ---- prep route
   int fused_prep = -1;           // HC_FUSED_PREP: -1 by batch size (cost model), 0 never fused, 1 always fused
   double fused_min_batch = -1;   // HC_FUSED_MIN_BATCH: a plain threshold in 720p-frame equivalents instead of the cost model
