@@ -348,6 +348,9 @@ typedef struct hc_launch_info {
   int32_t side_stream;                                       /* 1: the two cascade launches ran on two streams           */
   int32_t sq_stored;                                         /* 1: the squares' integral went to global memory           */
   int32_t nframes;
+  int32_t band_step[2];                                      /* grid rows per band of the two launches: the kernel's 16 (32), or one
+                                                                 less where that fits one more workgroup per CU (HC_BAND_TRIM)          */
+  int32_t lds_bytes[2];                                      /* LDS per workgroup of the two launches                    */
 } hc_launch_info;
 HC_API int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out);
 

@@ -1120,3 +1120,44 @@ def test_p16_build_and_standard_build_agree(pkg, oracle, synth, monkeypatch, nam
                 assert np.array_equal(raws[f], raw), (on, taps, f)
                 assert np.array_equal(got[f], grouped), (on, taps, f)
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["default", "alt2", "alt"])
+def test_trimmed_bands(pkg, oracle, synth, monkeypatch, name):
+    """A band may cover one grid row less than the kernel's 16 where that row of the tile is what keeps one more workgroup off
+    a CU (api_model.cpp, end of upload_model; HC_BAND_TRIM=0 switches it off): default's scan-step-2 launch runs 15-row bands
+    (40,552 bytes of LDS, four workgroups per CU, instead of 41,768 and three).  Whatever the library decides for a cascade, the
+    decision must be the one its rule states -- the launch report carries band rows and LDS bytes -- and every stage tap, raw
+    candidate and box must be the oracle's with the trim on and off (the last band of a level, the x-skip carry and the
+    segment walk of a single frame all see the shorter bands)."""
+    path = oracle.cascade_path(name)
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    frames = np.stack([synth.make_frames(["planted", "texture", "noise"][i % 3], 1, 720, 1280, first=900 + i)[0] for i in range(6)])
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        want = list(ex.map(lambda fr: oc.detect(fr, 1.1, 2, (30, 30), (0, 0), want_taps=True), frames))
+    steps = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("HC_BAND_TRIM", on)
+        for batch in (6, 1):                                 # whole bands; band segments (one frame)
+            ctx = pkg.Context(casc)
+            ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=batch, cand_capacity=1 << 13)
+            ctx.enable_stage_taps(True)
+            got = ctx.detect_host(frames[:batch])
+            raws = ctx.raw_candidates(batch)
+            info = ctx.last_launch()
+            steps[(on, batch)] = info["band_step"]
+            for k in range(2):
+                assert info["band_step"][k] in ((15, 16) if on == "1" else (16,)), info
+                if info["band_step"][k] == 15:               # the rule: the trim bought a workgroup per CU
+                    waves = 4 if k == 0 else 8
+                    per_cu = min(160 * 1024 // info["lds_bytes"][k], 32 // waves)
+                    assert per_cu * info["lds_bytes"][k] <= 160 * 1024 and per_cu > 1, info
+            for f in range(batch):
+                grouped, raw, otaps = want[f]
+                for li in range(len(ctx.levels())):
+                    assert np.array_equal(ctx.read_tap(f, li, pkg.TAP_STAGES), otaps[li]), (on, batch, f, li)
+                assert np.array_equal(raws[f], raw) and np.array_equal(got[f], grouped), (on, batch, f)
+            ctx.close()
+    if name == "default":
+        assert steps[("1", 6)][1] == 15 and steps[("0", 6)] == (16, 16), steps

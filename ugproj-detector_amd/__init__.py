@@ -67,7 +67,8 @@ class LaunchInfo(C.Structure):
                 ("pi_frame_chunk", C.c_int32), ("pi_remapped", C.c_int32), ("pi_tail_frames", C.c_int32),
                 ("casc_frame_chunk", C.c_int32), ("casc_remapped", C.c_int32), ("casc_tail_frames", C.c_int32),
                 ("variant", C.c_int32 * 2), ("compiled_stages", C.c_int32 * 2), ("segments", C.c_int32),
-                ("side_stream", C.c_int32), ("sq_stored", C.c_int32), ("nframes", C.c_int32)]
+                ("side_stream", C.c_int32), ("sq_stored", C.c_int32), ("nframes", C.c_int32),
+                ("band_step", C.c_int32 * 2), ("lds_bytes", C.c_int32 * 2)]
 
 
 VARIANT_NAMES = ("none", "f32", "int", "spec", "p16", "cv24", "cv24_tree", "cv24_window", "cv24_chains")       # hc_variant
@@ -420,7 +421,9 @@ class Context:
         ('variant': (step 1, step 2) names), prep / variance route names, and the frame-chunk values of both remaps"""
         info = LaunchInfo()
         _check(lib.hc_context_last_launch(self._h, C.byref(info)))
-        d = {k: getattr(info, k) for k, _ in LaunchInfo._fields_ if k not in ("variant", "compiled_stages")}
+        d = {k: getattr(info, k) for k, _ in LaunchInfo._fields_ if k not in ("variant", "compiled_stages", "band_step", "lds_bytes")}
+        d["band_step"] = tuple(info.band_step)
+        d["lds_bytes"] = tuple(info.lds_bytes)
         d["variant"] = tuple(VARIANT_NAMES[v] for v in info.variant)
         d["compiled_stages"] = tuple(info.compiled_stages)
         d["prep_route"] = PREP_NAMES[info.prep_route]

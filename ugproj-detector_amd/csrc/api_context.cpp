@@ -42,6 +42,7 @@ Knobs knobs_from_env() {
   getb("HC_CV24_FUSED", k.cv24_fused);
   getb("HC_CV24_SEG", k.cv24_seg);
   getb("HC_SHARE_VNF", k.share_vnf);
+  getb("HC_BAND_TRIM", k.band_trim);
   getb("HC_SIDE_PRIO", k.side_prio);
   getb("HC_COPY_PRIO", k.copy_prio);
   if (const char* e = getenv("HC_FUSED_MIN_BATCH")) k.fused_min_batch = atof(e);
@@ -260,10 +261,10 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   const bool cv24 = ctx->semantics == 1;
   if (cv24 && (prep_scales || leader)) return hc::set_err(HC_ERR_UNSUPPORTED, "shared prep passes exist for the OpenCV >= 4 semantics only");
   if (cv24 && (ctx->k.band_rows[0] != 16 || ctx->k.band_rows[1] != 16)) return hc::set_err(HC_ERR_UNSUPPORTED, "2.4 semantics: 16-row bands only");
-  int rc = cv24 ? hc::build_plan_cv24(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->k.band_rows[0],
-                                      ctx->k.band_rows[1], P, ctx->cv)
-                : hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->k.band_rows[0],
-                                 ctx->k.band_rows[1], P, prep_scales);
+  int rc = cv24 ? hc::build_plan_cv24(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_step[0],
+                                      ctx->band_step[1], P, ctx->cv)
+                : hc::build_plan(ctx->casc->model, rows, cols, scale_factor, min_w, min_h, max_w, max_h, ctx->band_step[0],
+                                 ctx->band_step[1], P, prep_scales);
   if (rc != HC_OK) return hc::set_err(rc, "cannot plan this configuration");
   for (const hc::DevLevel& L : P.levels)
     if (L.nx > 65535 || L.ny_all > 65535 || P.levels.size() > 255) return hc::set_err(HC_ERR_UNSUPPORTED, "frame too large");

@@ -255,6 +255,9 @@ int launch_cascades(hc_context* c, const Batch& b) {
     A.levels = c->d_levels;
     A.bands = seg ? c->d_seg_items[k] : c->d_band_items[k];
     A.nbands = seg ? c->n_seg_items[k] : (int)P.band_items[k].size();
+    A.band_step = c->band_step[k];
+    I.band_step[k] = c->band_step[k];
+    I.lds_bytes[k] = (int32_t)(k == 0 && c->p16 && !seg && c->semantics == 0 && c->k.debug_max_stages == 0 ? c->lds_bytes_p16 : c->lds_bytes[k]);
     A.nodes = c->d_nodes[k]; A.nodes_sparse = c->d_nodes_sparse[k]; A.stages = c->d_stages; A.kinds = c->d_kinds; A.nstages = (int)m.stages.size();
     const bool p16 = k == 0 && c->p16 && !seg && c->semantics == 0 && c->k.debug_max_stages == 0;
     if (p16) { A.nodes = c->d_nodes_p16; A.nodes_sparse = c->d_nodes_sparse_p16; A.kinds = c->d_kinds_p16; }

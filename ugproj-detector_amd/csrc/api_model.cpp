@@ -11,6 +11,8 @@
 namespace hc {
 
 // LDS tile geometry + per-geometry corner offsets of every node
+static constexpr size_t LDS_PER_CU = 160 * 1024;   // gfx950
+
 static hc::TileGeom make_geom(const hc::Model& m, int ystep, int band_rows) {
   hc::TileGeom g{};
   g.cols = (hc::TILE_POS - 1) * ystep + m.win_w + 1;
@@ -592,6 +594,24 @@ int upload_model(hc_context* c) {
         c->spec_id_p16 = id;
         c->p16 = true;
       }
+    }
+  }
+  // ---- a band one grid row short of the kernel's ROWS, where that row is what keeps one more workgroup off a CU (default's
+  // scan-step-2 workgroup: 41,768 bytes of LDS, 808 over a fourth per CU; with 15-row bands 40,552).  The tile loses `ystep`
+  // rows, nothing else moves (node offsets depend on the pitch only); the kernel stops at the band's own rows (CascadeArgs::band_step).
+  for (int k = 0; k < 2; k++) {
+    c->band_step[k] = c->k.band_rows[k];
+    if (!c->k.band_trim || cv24 || (k == 0 && c->p16) || c->k.band_rows[k] < 16) continue;
+    const auto per_cu = [&](size_t lds) { return std::min<size_t>(LDS_PER_CU / lds, 32 / (size_t)c->k.band_waves[k]); };
+    hc::TileGeom g = c->geom[k];
+    g.rows -= k + 1;
+    const size_t words = ((size_t)g.pitch * g.rows + 1) & ~(size_t)1;
+    const size_t lds = c->lds_bytes[k] - ((size_t)c->tile_words[k] - words) * 4;
+    if (per_cu(lds) > per_cu(c->lds_bytes[k])) {
+      c->geom[k] = g;
+      c->tile_words[k] = (int)words;
+      c->lds_bytes[k] = lds;
+      c->band_step[k] = c->k.band_rows[k] - 1;
     }
   }
   return HC_OK;

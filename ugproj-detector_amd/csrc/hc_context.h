@@ -42,6 +42,7 @@ namespace hc {
 struct Knobs {
   // ---- k_cascade tiling and modes
   int band_rows[2] = {16, 16};   // HC_BAND_ROWS1/2: grid rows per band, per scan-step class (index 0: step 1, 1: step 2)
+  bool band_trim = true;         // HC_BAND_TRIM: a band may cover one grid row less than the kernel's ROWS when that fits one more workgroup per CU
   int band_waves[2] = {4, 8};    // HC_BAND_WAVES1/2: wavefronts per cascade workgroup (4 or 8); measured best on MI355X
   int sparse_max = 32;           // HC_SPARSE_MAX: a tile's last <= this many windows take the finish
   int row_stages = 2;            // HC_ROW_STAGES: leading stages in row form (conflict-free LDS reads while 88 % of the windows live)
@@ -210,6 +211,7 @@ struct hc_context {
   hc::DevNode *d_nodes_p16 = nullptr, *d_nodes_sparse_p16 = nullptr;
   hc::DevStageKinds* d_kinds_p16 = nullptr;
   int last_compiled = 0;                 // stages that ran as compiled code in EVERY cascade launch of the last enqueued batch
+  int band_step[2] = {16, 16};           // grid rows per band of each scan-step class (upload_model: k.band_rows or one less)
   hc_launch_info last_launch = {};       // what the last enqueue launched (hc_context_last_launch)
   hc::DevStage* d_stages = nullptr;
   hc::DevStageKinds* d_kinds = nullptr;

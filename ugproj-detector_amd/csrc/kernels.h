@@ -20,6 +20,7 @@ struct CascadeArgs {
   const DevLevel* levels;
   const WorkItem* bands;      // bands of ONE ystep class (all share geometry g)
   int nbands;
+  int band_step;              // grid rows a band covers (<= the kernel's ROWS: hc_context::band_step); 0 = ROWS
   const DevNode* nodes;       // corner offsets resolved for g
   const DevNode* nodes_sparse; // the same records, exact stump stages in bank-spreading order: read by the sparse finish only
   const DevStage* stages;
@@ -69,7 +70,7 @@ int spec_register(const SpecUnit* u);
 // (a plug-in carries the kernel TEXT of its checkout: besides the struct sizes, HC_KERNEL_LAYOUT names the version of everything
 // the text assumes without a struct saying so -- LDS layout of k_cascade, node-word encodings, TileGeom meaning, the 16-bit
 // tile's tables.  Bump it with any such change in cascade_body.inc / spec_unit.inc / api_model.cpp's table builders.)
-constexpr int HC_KERNEL_LAYOUT = 7;
+constexpr int HC_KERNEL_LAYOUT = 8;
 constexpr int SPEC_PLUGIN_ABI = (HC_KERNEL_LAYOUT * 1000 + (int)sizeof(CascadeArgs)) * 4096 +
                                 (((int)sizeof(DevStage) * 31 + (int)sizeof(DevNode)) * 31 + (int)sizeof(TileGeom)) * 31 + (int)sizeof(DevTree) +
                                 (int)sizeof(DevStageKinds) * 7 + (int)sizeof(DevLevel);
