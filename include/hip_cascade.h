@@ -202,6 +202,16 @@ HC_API int  hc_context_configure_shared(hc_context* const* ctxs, int n, int rows
 HC_API int  hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t frame_stride_bytes,
                                     size_t row_step_bytes, int nframes);
 HC_API int  hc_context_set_rerun_on_overflow(hc_context* ctx, int allow);
+/* Rectangle grouping ON the device (cv::groupRectangles inside the call at reference
+ * src/tracker/detector.cc:25-31): with on != 0 every following batch of the context sorts, decodes and groups its raw
+ * candidates in its own last kernels (one workgroup per frame) and publishes the grouped boxes; hc_detect_batch_wait then
+ * copies them out and the host neither sorts nor groups.  Same boxes in the same order as the host grouping (tested
+ * against it and against the oracle).  A frame with more than 1024 raw candidates or more than 128 grouped boxes is
+ * grouped on the host as before; hc_context_group_host_frames says how many frames of the last waited batch that
+ * were (all of them while the switch is off or minNeighbors asks for the raw rectangles).  Default: the value of
+ * HC_DEVICE_GROUP when the context was created (1 unless set to 0). */
+HC_API int  hc_context_set_device_grouping(hc_context* ctx, int on);
+HC_API int  hc_context_group_host_frames(const hc_context* ctx);
 /* Same, from host memory (adds the H2D copy on the context stream; one copy for the whole batch when the
  * frames are tight and contiguous).  The copy is truly asynchronous -- and about 4x faster -- when the
  * frames live in page-locked memory: either allocate the frame pool with hc_host_alloc, or pin a pool the
@@ -351,6 +361,7 @@ typedef struct hc_launch_info {
   int32_t band_step[2];                                      /* grid rows per band of the two launches: the kernel's 16 (32), or one
                                                                  less where that fits one more workgroup per CU (HC_BAND_TRIM)          */
   int32_t lds_bytes[2];                                      /* LDS per workgroup of the two launches                    */
+  int32_t device_grouping;                                   /* 1: the batch grouped its rectangles on the device (K6)   */
 } hc_launch_info;
 HC_API int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out);
 
@@ -362,6 +373,12 @@ HC_API int hc_context_last_launch(const hc_context* ctx, hc_launch_info* out);
  * (*nstrips = 0 then).  semantics as hc_context_set_semantics. */
 HC_API int hc_debug_plan_strips(const hc_cascade* c, int rows, int cols, double scale_factor, int min_w, int min_h, int max_w,
                                 int max_h, int semantics, int comp_max, int32_t* strips, int cap, int* nstrips, int64_t* lds_bytes);
+
+/* Test entry of the result side alone (K6 and the host grouping): nkeys raw candidate keys
+ * (frame << 40 | level << 32 | grid_y << 16 | grid_x, in any order; levels as hc_context_levels lists them) take the
+ * place of a batch's candidates; hc_detect_batch_wait / hc_batch_raw_candidates then return what nframes frames with
+ * those candidates would have returned. */
+HC_API int hc_debug_enqueue_keys(hc_context* ctx, const unsigned long long* keys, int nkeys, int nframes);
 
 /* Device and pinned-host allocations the library has made in this process so far (hipMalloc / hipHostMalloc
  * calls): tests use it to show that a steady state allocates nothing. */

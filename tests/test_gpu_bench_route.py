@@ -465,3 +465,106 @@ def test_cpp_drivers_make_their_own_frames(pkg, oracle, synth, tmp_path):
                         "4", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr + r.stdout
     assert ("%d boxes per pass" % total) in r.stdout, r.stdout
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K6: rectangle grouping on the device (group_kernels.hip) -- the default result path of every batch in this file and in
+# the parity suites; here it is compared with the host grouping directly and pushed to its limits.
+
+def _key_cloud(rng, levels, nframes, per_frame, centres):
+    """raw candidate keys of `nframes` frames: `per_frame[f]` windows scattered around a few face centres over
+    neighbouring levels (what a detector's raw output looks like: many similar rectangles per face, some loners)"""
+    keys = []
+    for f in range(nframes):
+        cs = [(int(rng.integers(80, 1100)), int(rng.integers(60, 560)), int(rng.integers(0, len(levels) - 4))) for _ in range(centres)]
+        for _ in range(per_frame[f]):
+            cx, cy, l0 = cs[int(rng.integers(0, centres))]
+            if rng.random() < 0.1:      # a loner somewhere else
+                cx, cy = int(rng.integers(0, 1200)), int(rng.integers(0, 640))
+            li = min(len(levels) - 1, max(0, l0 + int(rng.integers(-1, 4))))
+            L = levels[li]
+            px = cx + int(rng.integers(-6, 7)) * max(1, int(L.scale))
+            py = cy + int(rng.integers(-6, 7)) * max(1, int(L.scale))
+            gx = min(max(int(px / L.scale) // L.ystep, 0), L.nx - 1)
+            gy = min(max(int(py / L.scale) // L.ystep, 0), L.ny - 1)
+            keys.append((f << 40) | (li << 32) | (gy << 16) | gx)
+    keys = np.array(keys, np.uint64)
+    rng.shuffle(keys)
+    return keys
+
+
+@pytest.mark.parametrize("cv24", [False, True])
+def test_device_grouping_on_key_clouds(pkg, oracle, cv24):
+    """The result side alone, fed with synthetic candidate keys: frames with 0, 1, 2, 63, 64, 65, 300, 1000 and 1024 raw
+    rectangles (one bin is 1024) in shuffled order.  Device grouping, host grouping and the oracle's groupRectangles on the
+    decoded rectangles agree box for box, order included; raw candidates come back in upstream's order on both paths;
+    minNeighbors 1, 2 and 5."""
+    casc = pkg.Cascade(oracle.cascade_path("alt"))
+    rng = np.random.default_rng(77)
+    counts = [0, 1, 2, 63, 64, 65, 300, 1000, 1024, 17, 0, 129]
+    B = len(counts)
+    for mn in (2, 1, 5):
+        dev, host = pkg.Context(casc), pkg.Context(casc)
+        for c in (dev, host):
+            if cv24:
+                c.set_semantics(True)
+            c.configure(720, 1280, 1.1, mn, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 10)
+        dev.set_device_grouping(True)
+        host.set_device_grouping(False)
+        keys = _key_cloud(rng, dev.levels(), B, counts, centres=5)
+        assert len(keys) == sum(counts)
+        dev.enqueue_keys(keys, B)
+        gd = dev.wait(B)
+        assert dev.group_host_frames() == 0 and dev.last_launch()["device_grouping"] == 1
+        host.enqueue_keys(keys, B)
+        gh = host.wait(B)
+        assert host.group_host_frames() == B and host.last_launch()["device_grouping"] == 0
+        rd, rh = dev.raw_candidates(B), host.raw_candidates(B)
+        nb = 0
+        for f in range(B):
+            assert len(rd[f]) == counts[f] and np.array_equal(rd[f], rh[f]), "frame %d raw rectangles" % f
+            assert np.array_equal(gd[f], gh[f]), "minNeighbors %d frame %d: device and host grouping differ" % (mn, f)
+            want = oracle.group_rectangles(rd[f], mn) if len(rd[f]) else np.zeros((0, 4), np.int32)
+            assert np.array_equal(gd[f], want), "minNeighbors %d frame %d: device grouping vs the oracle's groupRectangles" % (mn, f)
+            nb += len(gd[f])
+        assert nb >= 10, "the clouds must form groups (got %d boxes)" % nb
+
+
+def test_device_grouping_leaves_overflowing_frames_to_the_host(pkg, oracle, synth, monkeypatch):
+    """Bins of 8 raw candidates / output slots of 2 boxes (test knobs): the planted frames overflow and are grouped on the
+    host from the raw keys, the noise frames stay on the device -- one batch mixes both; boxes and raw candidates of every
+    frame equal the oracle's either way, and the counters say which path each frame took."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 12
+    kinds = ["planted", "noise", "texture"]
+    frames = np.stack([synth.make_frames(kinds[i % 3], 1, 720, 1280, first=300 + i)[0] for i in range(B)])
+    want = _oracle_many(oc, frames, False)
+    for env, lo, hi in (({"HC_GROUP_BIN_CAP": "8"}, 1, B - 1), ({"HC_GROUP_OUT_CAP": "1"}, 1, B - 1), ({}, 0, 0)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = pkg.Context(casc)
+        for k in env:
+            monkeypatch.delenv(k)
+        ctx.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)
+        for rnd in range(2):
+            got = ctx.detect_host(frames)
+            assert lo <= ctx.group_host_frames() <= hi, "%r: %d frames went to the host" % (env, ctx.group_host_frames())
+            assert ctx.last_launch()["device_grouping"] == 1
+            raws = ctx.raw_candidates(B)
+            for f in range(B):
+                assert np.array_equal(raws[f], want[f][1]), "%r frame %d raw candidates" % (env, f)
+                assert np.array_equal(got[f], want[f][0]), "%r frame %d boxes" % (env, f)
+    # the switch off: same boxes, every frame grouped on the host
+    ctx.set_device_grouping(False)
+    got = ctx.detect_host(frames)
+    assert ctx.group_host_frames() == B and ctx.last_launch()["device_grouping"] == 0
+    for f in range(B):
+        assert np.array_equal(got[f], want[f][0])
+    # minNeighbors 0: the raw rectangles are the result, nothing to group on either side
+    ctx0 = pkg.Context(casc)
+    ctx0.configure(720, 1280, 1.1, 0, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)
+    got0 = ctx0.detect_host(frames)
+    assert ctx0.last_launch()["device_grouping"] == 0
+    for f in range(B):
+        assert np.array_equal(got0[f], want[f][1])

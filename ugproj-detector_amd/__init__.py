@@ -68,7 +68,7 @@ class LaunchInfo(C.Structure):
                 ("casc_frame_chunk", C.c_int32), ("casc_remapped", C.c_int32), ("casc_tail_frames", C.c_int32),
                 ("variant", C.c_int32 * 2), ("compiled_stages", C.c_int32 * 2), ("segments", C.c_int32),
                 ("side_stream", C.c_int32), ("sq_stored", C.c_int32), ("nframes", C.c_int32),
-                ("band_step", C.c_int32 * 2), ("lds_bytes", C.c_int32 * 2)]
+                ("band_step", C.c_int32 * 2), ("lds_bytes", C.c_int32 * 2), ("device_grouping", C.c_int32)]
 
 
 VARIANT_NAMES = ("none", "f32", "int", "spec", "p16", "cv24", "cv24_tree", "cv24_window", "cv24_chains")       # hc_variant
@@ -105,6 +105,9 @@ _SIGS = {
     "hc_detect_multiscale_reread": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "hc_debug_alloc_count": (C.c_longlong, []),
     "hc_context_set_rerun_on_overflow": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_context_set_device_grouping": (C.c_int, [C.c_void_p, C.c_int]),
+    "hc_context_group_host_frames": (C.c_int, [C.c_void_p]),
+    "hc_debug_enqueue_keys": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "hc_context_set_semantics": (C.c_int, [C.c_void_p, C.c_int]),
     "hc_convert_bgr2gray": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t]),
     "hc_boxes_save": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -343,6 +346,20 @@ class Context:
         """False: OpenCV >= 4 (default); True: OpenCV 2.4.x (hc_context_set_semantics); call before configure()"""
         _check(lib.hc_context_set_semantics(self._h, 1 if cv24 else 0))
         self.cv24 = bool(cv24)
+
+    def set_device_grouping(self, on=True):
+        """rectangles grouped by the batch's own last kernels (K6) instead of on the host; same boxes, same order"""
+        _check(lib.hc_context_set_device_grouping(self._h, int(on)))
+
+    def group_host_frames(self):
+        """frames of the last waited batch whose rectangles the HOST grouped (0 when the device grouped them all)"""
+        return int(lib.hc_context_group_host_frames(self._h))
+
+    def enqueue_keys(self, keys, nframes):
+        """test entry: raw candidate keys (frame << 40 | level << 32 | gy << 16 | gx) in place of a batch's candidates"""
+        keys = np.ascontiguousarray(keys, np.uint64)
+        _check(lib.hc_debug_enqueue_keys(self._h, keys.ctypes.data, len(keys), nframes))
+        self._n = nframes
 
     def set_rerun_on_overflow(self, allow=True):
         """caller-owned device frames stay valid and unmodified until wait(): a candidate-workspace overflow re-runs by itself"""

@@ -45,6 +45,9 @@ Knobs knobs_from_env() {
   getb("HC_BAND_TRIM", k.band_trim);
   getb("HC_SIDE_PRIO", k.side_prio);
   getb("HC_COPY_PRIO", k.copy_prio);
+  getb("HC_DEVICE_GROUP", k.device_group);
+  geti("HC_GROUP_BIN_CAP", k.group_bin_cap, 1, HC_GROUP_BIN);
+  geti("HC_GROUP_OUT_CAP", k.group_out_cap, 1, HC_GROUP_OUT);
   if (const char* e = getenv("HC_FUSED_MIN_BATCH")) k.fused_min_batch = atof(e);
   geti("HC_SIDE_MAX_BATCH", k.side_max_batch, 0, 1 << 20);
   geti("HC_SEG_MAX_BATCH", k.seg_max_batch, 0, 1 << 20);
@@ -121,6 +124,21 @@ int ensure_taps(hc_context* c) {
   if (c->d_taps) return HC_OK;
   return dev_alloc(&c->d_taps, (size_t)c->max_batch * c->plan.grid_elems);
 }
+// K6 workspace: bins, level table, output slots
+int ensure_group(hc_context* c) {
+  if (c->d_gbins) return HC_OK;
+  const hc::Plan& P = c->plan;
+  std::vector<hc::GroupLevel> gl(P.levels.size());
+  for (size_t i = 0; i < gl.size(); i++) {
+    const hc::DevLevel& L = P.levels[i];
+    gl[i] = hc::GroupLevel{L.scale, L.ystep, L.win_w, L.win_h, c->semantics == 1 ? c->cv.lv[i].factor : (double)L.scale};
+  }
+  int rc;
+  if ((rc = dev_upload(&c->d_glevels, gl))) return rc;
+  if ((rc = host_alloc_coherent((void**)&c->h_gboxes, (size_t)c->max_batch * HC_GROUP_OUT * sizeof(hc::GroupBox)))) return rc;
+  if ((rc = host_alloc_coherent((void**)&c->h_gcount, (size_t)c->max_batch * sizeof(unsigned int)))) return rc;
+  return dev_alloc(&c->d_gbins, (size_t)c->max_batch * HC_GROUP_BIN);
+}
 
 }  // namespace hc
 
@@ -151,6 +169,11 @@ void hc_context::free_workspace() {
   d_resize_items = d_row_items = d_col_items = d_var_items = d_band_items[0] = d_band_items[1] = nullptr;
   d_seg_items[0] = d_seg_items[1] = nullptr;
   d_cand = nullptr; d_count = nullptr; d_ticket = nullptr;
+  if (d_gbins) (void)hipFree(d_gbins);
+  if (d_glevels) (void)hipFree(d_glevels);
+  if (h_gboxes) (void)hipHostFree(h_gboxes);
+  if (h_gcount) (void)hipHostFree(h_gcount);
+  d_gbins = nullptr; d_glevels = nullptr; h_gboxes = nullptr; h_gcount = nullptr; group_ran = false;
   d_strips = nullptr; d_carry = nullptr; d_strip_progress = nullptr; use_strips = false; strips = hc::StripPlan{};
   if (h_cand) (void)hipHostFree(h_cand);
   if (h_pub) (void)hipHostFree(h_pub);
@@ -186,6 +209,7 @@ int hc_context_create(const hc_cascade* c, int device, void* stream, hc_context*
   ctx->casc = c;
   ctx->device = device;
   ctx->k = hc::knobs_from_env();       // every tuning variable, once: nothing below reads the environment again
+  ctx->device_group = ctx->k.device_group;
   if (stream) { ctx->stream = (hipStream_t)stream; ctx->own_stream = false; }
   else {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -323,7 +347,7 @@ int configure_impl(hc_context* ctx, int rows, int cols, double scale_factor, int
   else if ((rc = dev_alloc(&ctx->d_vnf, cv24 ? 1 : B * P.grid_elems))) return rc;
   ctx->cand_cap = B * ctx->cand_per_frame;
   if ((rc = dev_alloc(&ctx->d_cand, ctx->cand_cap))) return rc;
-  if ((rc = dev_alloc(&ctx->d_count, 1))) return rc;
+  if ((rc = dev_alloc(&ctx->d_count, 1 + B))) return rc;   // the batch's candidate count, then one count per frame (K6 bins)
   if (!cv24 && !ctx->vnf_shared) HIPCHK(hipMemset(ctx->d_vnf, 0, std::max<size_t>(B * P.grid_elems, 1) * 4));
   if ((rc = dev_upload(&ctx->d_levels, P.levels))) return rc;
   if ((rc = dev_upload(&ctx->d_xtab, P.xtab))) return rc;
@@ -395,6 +419,15 @@ int hc_context_set_rerun_on_overflow(hc_context* ctx, int allow) {
   ctx->rerun_caller_frames = allow != 0;
   return HC_OK;
 }
+
+int hc_context_set_device_grouping(hc_context* ctx, int on) {
+  if (!ctx) return hc::set_err(HC_ERR_ARG, "null context");
+  if (ctx->pending) return hc::set_err(HC_ERR_STATE, "a batch is in flight");
+  ctx->device_group = on != 0;
+  return HC_OK;
+}
+
+int hc_context_group_host_frames(const hc_context* ctx) { return ctx ? ctx->last_group_host_frames : 0; }
 
 int hc_context_set_semantics(hc_context* ctx, int semantics) {
   if (!ctx) return hc::set_err(HC_ERR_ARG, "null context");

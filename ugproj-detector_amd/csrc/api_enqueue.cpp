@@ -318,6 +318,13 @@ int publish_results(hc_context* c) {
   // (the strip kernel's error word sits behind the row counts of the batch it just ran with)
   const unsigned int* strip_err = c->last_launch.variance_route == HC_VAR_RING_STRIPS || c->strips_ran
                                       ? c->d_strip_progress + (size_t)c->last_launch.nframes * c->strips.strips.size() : nullptr;
+  if (c->group_ran) {
+    if (int e = launch_group(c->stream, c->last_launch.nframes, c->d_count, c->d_cand, (unsigned int)std::min<size_t>(c->cand_cap, 0xffffffffu),
+                             c->d_count + 1, c->d_gbins, c->d_glevels, c->semantics, group_threshold(c), c->h_gboxes, c->h_gcount,
+                             c->k.group_bin_cap, c->k.group_out_cap))
+      return hip_fail("k_group", e);
+    c->last_launch.device_grouping = 1;
+  }
   if (int e = launch_publish(c->stream, c->d_count, c->d_cand, (unsigned int)std::min<size_t>(c->cand_cap, 0xffffffffu), c->h_cand,
                              c->h_pub, ++c->pub_seq, c->d_ticket, strip_err))
     return hip_fail("k_publish", e);
@@ -342,7 +349,11 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   b.equiv = (double)nframes * (double)P.rows * (double)P.cols / (1280.0 * 720.0);
   b.pyr_stride = (size_t)P.pyr_bytes; b.int_stride = (size_t)P.int_words; b.grid_stride = (size_t)P.grid_elems;
   c->timed_last = b.timed;
-  HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int), s));
+  // K6: the batch groups its own rectangles unless the raw ones are the result (minNeighbors) or a debug build truncates the cascade
+  c->group_ran = c->device_group && group_threshold(c) > 0 && !P.levels.empty() && c->k.debug_max_stages == 0;
+  if (c->group_ran)
+    if (int rc = ensure_group(c)) return rc;
+  HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int) * (c->group_ran ? 1 + (size_t)nframes : 1), s));
   if (!P.levels.empty()) {
     const bool cv24 = c->semantics == 1;
     const bool cv24_fused = cv24 && cv24_takes_fused(c, nframes);
@@ -391,6 +402,35 @@ int hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, size_t fra
   HIPCHK(hipSetDevice(ctx->device));
   if (int rc = hc::shared_enqueue_check(ctx, d_frames, nframes)) return rc;
   return hc::enqueue_device(ctx, d_frames, frame_stride_bytes, row_step_bytes, nframes);
+}
+
+// Test entry of the result side alone: nkeys raw candidate keys (frame << 40 | level << 32 | gy << 16 | gx, any order) take the
+// place of a batch's candidates and go through grouping + publication exactly as the cascade kernels' own would.
+int hc_debug_enqueue_keys(hc_context* ctx, const unsigned long long* keys, int nkeys, int nframes) {
+  if (!ctx || !ctx->configured) return hc::set_err(HC_ERR_STATE, "context not configured");
+  if (!keys || nkeys < 0 || nframes <= 0 || nframes > ctx->max_batch || (size_t)nkeys > ctx->cand_cap)
+    return hc::set_err(HC_ERR_ARG, "bad key list / batch size");
+  if (ctx->pending) return hc::set_err(HC_ERR_STATE, "previous batch not waited");
+  for (int i = 0; i < nkeys; i++)
+    if ((int)(keys[i] >> 40) >= nframes || ((keys[i] >> 32) & 0xFF) >= ctx->plan.levels.size()) return hc::set_err(HC_ERR_ARG, "key out of range");
+  HIPCHK(hipSetDevice(ctx->device));
+  hc_context* c = ctx;
+  c->inflight_src = nullptr;
+  c->last_launch = hc_launch_info{};
+  c->last_launch.nframes = nframes;
+  c->strips_ran = false;
+  c->timed_last = false;
+  c->group_ran = c->device_group && hc::group_threshold(c) > 0;
+  if (c->group_ran)
+    if (int rc = hc::ensure_group(c)) return rc;
+  HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int) * (1 + (size_t)nframes), c->stream));
+  const unsigned int n = (unsigned int)nkeys;
+  HIPCHK(hipMemcpyAsync(c->d_count, &n, sizeof n, hipMemcpyHostToDevice, c->stream));
+  if (nkeys) HIPCHK(hipMemcpyAsync(c->d_cand, keys, (size_t)nkeys * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));     // (n and keys are the caller's pageable memory)
+  if (int rc = hc::publish_results(c)) return rc;
+  c->pending = nframes;
+  return HC_OK;
 }
 
 int hc_detect_batch_enqueue_host(hc_context* ctx, const uint8_t* h_frames, size_t frame_stride_bytes,

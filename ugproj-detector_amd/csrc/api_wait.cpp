@@ -48,6 +48,54 @@ static int wait_published(hc_context* ctx) {
   }
 }
 
+// ---- raw candidates: keys -> upstream's order -> rectangles --------------------------------------------------------
+static hc_rect decode_key(const hc_context* ctx, unsigned long long k) {
+  const hc::DevLevel& L = ctx->plan.levels[(k >> 32) & 0xFF];
+  const int gy = (int)((k >> 16) & 0xFFFF), gx = (int)(k & 0xFFFF);
+  if (ctx->semantics == 1) {
+    // 2.4 (B.9): cvRound(x * factor) with the f64 factor of the scale loop
+    const double factor = ctx->cv.lv[(k >> 32) & 0xFF].factor;
+    return hc_rect{(int)std::nearbyint(gx * L.ystep * factor), (int)std::nearbyint(gy * L.ystep * factor), L.win_w, L.win_h};
+  }
+  // Rect(cvRound(x*scale), cvRound(y*scale), winSize): int -> f32 times f32 scale
+  return hc_rect{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale), (int)std::nearbyintf((float)(gy * L.ystep) * L.scale),
+                 L.win_w, L.win_h};
+}
+
+// canonical single-thread order: frame -> scale -> y -> x  == ascending key; last_raw_ofs = frame boundaries in it
+static void sort_raw_keys(hc_context* ctx) {
+  std::vector<unsigned long long>& K = ctx->raw_keys;
+  std::sort(K.begin(), K.end());
+  const int nframes = ctx->last_frames;
+  ctx->last_raw_ofs.assign(nframes + 1, 0);
+  size_t i = 0;
+  for (int f = 0; f < nframes; f++) {
+    ctx->last_raw_ofs[f] = (int32_t)i;
+    while (i < K.size() && (int)(K[i] >> 40) == f) i++;
+  }
+  ctx->last_raw_ofs[nframes] = (int32_t)i;
+}
+
+// the raw rectangles of the last waited batch (hc_batch_raw_candidates, frames the device left to the host)
+static void decode_raw(hc_context* ctx) {
+  if (ctx->raw_decoded) return;
+  sort_raw_keys(ctx);
+  ctx->last_raw.resize(ctx->raw_keys.size());
+  for (size_t i = 0; i < ctx->raw_keys.size(); i++) ctx->last_raw[i] = decode_key(ctx, ctx->raw_keys[i]);
+  ctx->raw_decoded = true;
+}
+
+// the grouping threshold a context's batches run with: 0 = the raw rectangles are the result
+int group_threshold(const hc_context* ctx) {
+  if (ctx->semantics == 1) return ctx->min_neighbors != 0 ? std::max(ctx->min_neighbors, 1) : 0;   // 2.4: minNeighbors 0 = raw
+  return std::max(ctx->min_neighbors, 0);
+}
+
+static void group_frame(const hc_context* ctx, std::vector<hc_rect>& grp) {
+  const int thr = group_threshold(ctx);
+  if (thr > 0) hc::group_rectangles(grp, thr, 0.2);   // GROUP_EPS upstream
+}
+
 // waits for the enqueued batch and groups its candidates: grouped[f] = boxes of frame f
 int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   HIPCHK(hipSetDevice(ctx->device));
@@ -90,48 +138,45 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   if (ctx->timed_last && !ctx->plan.levels.empty())
     for (int i = 0; i < HC_NKERNELS; i++) HIPCHK(hipEventElapsedTime(&ctx->last_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   ctx->last_frames = nframes;
+  // the raw keys leave the published buffer now (the next batch's kernels overwrite it); sorted and decoded when needed
+  ctx->raw_keys.assign(ctx->h_cand, ctx->h_cand + count);
+  ctx->raw_decoded = false;
   ctx->last_raw.clear();
   ctx->last_raw_ofs.assign(nframes + 1, 0);
-  // canonical single-thread order: frame -> scale -> y -> x  == ascending key
-  std::sort(ctx->h_cand, ctx->h_cand + count);
-  const hc::Plan& P = ctx->plan;
-  // frame boundaries inside the sorted key list
-  std::vector<size_t> first(nframes + 1, count);
-  {
-    size_t i = 0;
-    for (int f = 0; f < nframes; f++) {
-      first[f] = i;
-      while (i < count && (int)(ctx->h_cand[i] >> 40) == f) i++;
-    }
-    first[nframes] = i;
-  }
-  ctx->last_raw.resize(count);
   grouped.assign(nframes, {});
+  ctx->last_group_host_frames = nframes;
+  if (ctx->group_ran) {
+    // K6: the batch grouped its own candidates (group_kernels.hip); the boxes sit in page-locked memory, frame by frame.
+    // A frame whose candidates overflowed its bin (or its boxes their slot) carries 0xFFFFFFFF and is grouped here.
+    static_assert(sizeof(hc_rect) == sizeof(GroupBox), "hc_rect and GroupBox share a layout");
+    std::vector<int> left;
+    for (int f = 0; f < nframes; f++) {
+      const unsigned int nb = ctx->h_gcount[f];
+      if (nb == 0xFFFFFFFFu) { left.push_back(f); continue; }
+      const hc_rect* src = reinterpret_cast<const hc_rect*>(ctx->h_gboxes) + (size_t)f * HC_GROUP_OUT;
+      grouped[f].assign(src, src + nb);
+    }
+    ctx->last_group_host_frames = (int)left.size();
+    if (left.empty()) return HC_OK;
+    decode_raw(ctx);
+    for (int f : left) {
+      grouped[f].assign(ctx->last_raw.begin() + ctx->last_raw_ofs[f], ctx->last_raw.begin() + ctx->last_raw_ofs[f + 1]);
+      group_frame(ctx, grouped[f]);
+    }
+    return HC_OK;
+  }
+  sort_raw_keys(ctx);
+  ctx->last_raw.resize(count);
   auto do_frame = [&](int f) {
     std::vector<hc_rect>& grp = grouped[f];
-    grp.reserve(first[f + 1] - first[f]);
-    for (size_t i = first[f]; i < first[f + 1]; i++) {
-      const unsigned long long k = ctx->h_cand[i];
-      const hc::DevLevel& L = P.levels[(k >> 32) & 0xFF];
-      const int gy = (int)((k >> 16) & 0xFFFF), gx = (int)(k & 0xFFFF);
-      hc_rect r;
-      if (ctx->semantics == 1) {
-        // 2.4 (B.9): cvRound(x * factor) with the f64 factor of the scale loop
-        const double factor = ctx->cv.lv[(k >> 32) & 0xFF].factor;
-        r = hc_rect{(int)std::nearbyint(gx * L.ystep * factor), (int)std::nearbyint(gy * L.ystep * factor), L.win_w, L.win_h};
-      } else {
-        // Rect(cvRound(x*scale), cvRound(y*scale), winSize): int -> f32 times f32 scale
-        r = hc_rect{(int)std::nearbyintf((float)(gx * L.ystep) * L.scale), (int)std::nearbyintf((float)(gy * L.ystep) * L.scale),
-                    L.win_w, L.win_h};
-      }
+    const size_t a = (size_t)ctx->last_raw_ofs[f], b = (size_t)ctx->last_raw_ofs[f + 1];
+    grp.reserve(b - a);
+    for (size_t i = a; i < b; i++) {
+      const hc_rect r = decode_key(ctx, ctx->raw_keys[i]);
       grp.push_back(r);
       ctx->last_raw[i] = r;
     }
-    if (ctx->semantics == 1) {
-      if (ctx->min_neighbors != 0) hc::group_rectangles(grp, std::max(ctx->min_neighbors, 1), 0.2);   // 2.4: minNeighbors 0 = raw
-    } else {
-      hc::group_rectangles(grp, ctx->min_neighbors, 0.2);   // GROUP_EPS upstream
-    }
+    group_frame(ctx, grp);
   };
   if (nframes >= 4 && count >= 512 && ctx->k.host_threads > 1) {
     if (!ctx->pool) ctx->pool.reset(new WorkerPool(ctx->k.host_threads - 1));
@@ -139,9 +184,11 @@ int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped) {
   } else {
     for (int f = 0; f < nframes; f++) do_frame(f);
   }
-  for (int f = 0; f < nframes; f++) ctx->last_raw_ofs[f + 1] = (int32_t)first[f + 1];
+  ctx->raw_decoded = true;
   return HC_OK;
 }
+
+void decode_raw_public(hc_context* ctx) { decode_raw(ctx); }
 
 int emit_rects(const std::vector<std::vector<hc_rect>>& grouped, hc_rect* out, int out_capacity, int32_t* offsets) {
   int total = 0;
@@ -171,6 +218,7 @@ int hc_detect_batch_wait(hc_context* ctx, hc_rect* out, int out_capacity, int32_
 
 int hc_batch_raw_candidates(hc_context* ctx, hc_rect* out, int out_capacity, int32_t* offsets) {
   if (!ctx || !offsets) return hc::set_err(HC_ERR_ARG, "null argument");
+  hc::decode_raw_public(ctx);
   if ((int)ctx->last_raw.size() > out_capacity) return hc::set_err(HC_ERR_CAPACITY, "output rectangle buffer too small");
   for (size_t i = 0; i < ctx->last_raw.size(); i++) out[i] = ctx->last_raw[i];
   for (size_t i = 0; i < ctx->last_raw_ofs.size(); i++) offsets[i] = ctx->last_raw_ofs[i];

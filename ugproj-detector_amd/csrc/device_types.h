@@ -94,4 +94,11 @@ struct DevStage { int32_t first, count; float thr; int16_t exact, pair; double b
 static_assert(sizeof(DevStage) == 32, "DevStage layout");
 struct DevTree { int32_t first_node, nnodes, first_leaf, pad; };   // pad bit 0 (pair form): the root's LEFT branch is the second node
 
+// On-device rectangle grouping (group_kernels.hip): a frame's bin holds HC_GROUP_BIN raw candidate keys, its output slot
+// HC_GROUP_OUT grouped boxes; a frame that exceeds either is flagged and grouped on the host.
+#define HC_GROUP_BIN 1024
+#define HC_GROUP_OUT 128
+struct GroupLevel { float scale; int32_t ystep, win_w, win_h; double factor; };   // factor: the 2.4 generation's f64 scale
+struct GroupBox { int32_t x, y, width, height; };                                 // == hc_rect
+
 }  // namespace hc

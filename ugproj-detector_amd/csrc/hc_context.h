@@ -76,6 +76,9 @@ struct Knobs {
   bool side_prio = true;         // HC_SIDE_PRIO=0: the side stream at normal priority
   bool copy_prio = true;         // HC_COPY_PRIO=0: the copy stream at normal priority
   int host_threads = 4;          // HC_HOST_THREADS: post-processing threads per context
+  bool device_group = true;      // HC_DEVICE_GROUP=0: rectangles are grouped on the host (hc_context_set_device_grouping)
+  int group_bin_cap = HC_GROUP_BIN;   // HC_GROUP_BIN_CAP / HC_GROUP_OUT_CAP (tests): raw candidates / grouped boxes per frame beyond
+  int group_out_cap = HC_GROUP_OUT;   //   which a frame is left to the host, at most the compiled sizes
 };
 Knobs knobs_from_env();
 // HC_SYNC_CONTEXTS, read when a cascade is loaded: how many contexts the synchronous calls keep per cascade
@@ -258,8 +261,21 @@ struct hc_context {
   bool sq_valid = true;           // the last batch left the squares' integral in d_sq (the fused prep kernel keeps it in LDS unless a tap asks)
   hipEvent_t ev[HC_NKERNELS + 1] = {};
   float last_ms[HC_NKERNELS] = {};
+  // Raw candidates of the last waited batch: the published keys are copied out at the wait and sorted / decoded into
+  // last_raw only when somebody asks (hc_batch_raw_candidates, a frame the device left to the host, host grouping)
+  std::vector<unsigned long long> raw_keys;
+  bool raw_decoded = true;
   std::vector<hc_rect> last_raw;
   std::vector<int32_t> last_raw_ofs;
+  // K6: rectangle grouping on the device (group_kernels.hip).  Per-frame bins of raw keys, the level table the decode
+  // needs, and per-frame output slots + box counts in coherent page-locked memory (made on first use).
+  bool device_group = true;              // hc_context_set_device_grouping (initially Knobs::device_group)
+  bool group_ran = false;                // the batch in flight groups its own rectangles
+  int last_group_host_frames = 0;        // frames of the last waited batch that were grouped on the host
+  unsigned long long* d_gbins = nullptr;
+  hc::GroupLevel* d_glevels = nullptr;
+  hc::GroupBox* h_gboxes = nullptr;
+  unsigned int* h_gcount = nullptr;
   std::unique_ptr<WorkerPool> pool;   // host post-processing workers (created on first multi-frame wait)
 
   void free_workspace();
@@ -296,6 +312,7 @@ PrepKnobs prep_knobs(const hc_context* c);
 int ensure_frames(hc_context* c);
 int ensure_pyr(hc_context* c);
 int ensure_taps(hc_context* c);
+int ensure_group(hc_context* c);
 
 // ---- api_enqueue.cpp
 int shared_enqueue_check(hc_context* c, const void* frames, int nframes);
@@ -304,6 +321,8 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
 // ---- api_wait.cpp
 int wait_event_polling(hipEvent_t ev);
 int wait_core(hc_context* ctx, std::vector<std::vector<hc_rect>>& grouped);
+int group_threshold(const hc_context* ctx);    // 0: the raw rectangles are the result (nothing to group)
+void decode_raw_public(hc_context* ctx);
 int emit_rects(const std::vector<std::vector<hc_rect>>& grouped, hc_rect* out, int out_capacity, int32_t* offsets);
 
 // ---- api_faces.cpp

@@ -147,6 +147,11 @@ int launch_integral_cols(hipStream_t st, int nframes, int nitems, const DevLevel
 int launch_publish(hipStream_t st, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
                    unsigned long long* h_cand, unsigned int* h_pub, unsigned int seq, unsigned int* ticket,
                    const unsigned int* err = nullptr);
+// K6: raw candidate keys -> per-frame bins -> grouped boxes and per-frame counts in page-locked host memory (0xFFFFFFFF: the
+// frame overflowed a bin or its output slot and is left to the host); frame_count must be zero on entry
+int launch_group(hipStream_t st, int nframes, const unsigned int* count, const unsigned long long* cand, unsigned int cap,
+                 unsigned int* frame_count, unsigned long long* bins, const GroupLevel* levels, int semantics, int threshold,
+                 GroupBox* h_boxes, unsigned int* h_nboxes, int bin_cap = HC_GROUP_BIN, int out_cap = HC_GROUP_OUT);
 int launch_variance(hipStream_t st, int nframes, int nitems, const DevLevel* levels, const WorkItem* items,
                     const uint32_t* sum, const uint32_t* sq, size_t int_stride, int norm_w, int norm_h,
                     float* vnf, size_t grid_stride);
