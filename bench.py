@@ -634,7 +634,7 @@ def run_e2e(E, args, batches=12, B=256):
     return {"value": round(batches * B / dt, 1), "unit": "frames/s", "batches": batches, "frames_per_batch": B,
             "ms_per_batch": round(1e3 * dt / batches, 3),
             "path": "page-locked host frames -> hc_detect_batch_enqueue_host (H2D on the slot's upload stream) -> kernels -> "
-                    "published candidates -> host grouping; two slots on one stream",
+                    "published candidates + boxes grouped on the device (K6); two slots on one stream",
             "parity": {"frames_checked": len(pos), "bit_exact": bool(ok)}}
 
 

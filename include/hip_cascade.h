@@ -203,7 +203,8 @@ HC_API int  hc_detect_batch_enqueue(hc_context* ctx, const uint8_t* d_frames, si
                                     size_t row_step_bytes, int nframes);
 HC_API int  hc_context_set_rerun_on_overflow(hc_context* ctx, int allow);
 /* Rectangle grouping ON the device (cv::groupRectangles inside the call at reference
- * src/tracker/detector.cc:25-31): with on != 0 every following batch of the context sorts, decodes and groups its raw
+ * src/tracker/detector.cc:25-31): with on != 0 every following batch of at least 8 frames (HC_GROUP_MIN_BATCH; smaller
+ * batches and the synchronous calls are latency-bound and grouped faster by the host) sorts, decodes and groups its raw
  * candidates in its own last kernels (one workgroup per frame) and publishes the grouped boxes; hc_detect_batch_wait then
  * copies them out and the host neither sorts nor groups.  Same boxes in the same order as the host grouping (tested
  * against it and against the oracle).  A frame with more than 1024 raw candidates or more than 128 grouped boxes is

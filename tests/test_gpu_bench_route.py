@@ -74,6 +74,8 @@ def test_bench_route_taps_720p_batch24(pkg, oracle, synth):
     ctx.enable_stage_taps(False)
     assert ctx.compiled_stages() > 0, "the stock cascade must run its compiled early stages on this route"
     got2 = ctx.detect_host(frames)
+    assert ctx.last_launch()["device_grouping"] == 1 and ctx.group_host_frames() == 0, \
+        "a batch of 24 frames groups its rectangles on the device (K6) by policy"
     raws2 = ctx.raw_candidates(B)
     for f in range(B):
         assert np.array_equal(raws2[f], want[f][1]), "no-tap kernel: frame %d raw candidates" % f
@@ -113,6 +115,7 @@ def test_bench_shape_160_frames_every_chunk(pkg, oracle, synth):
     assert (info["pi_frame_chunk"], info["pi_remapped"], info["pi_tail_frames"]) == (32, 1, 0), info
     assert (info["casc_frame_chunk"], info["casc_remapped"], info["casc_tail_frames"]) == (128, 1, 32), info
     assert info["variant"] == ("p16", "spec") and info["segments"] == 0 and info["sq_stored"] == 0, info
+    assert info["device_grouping"] == 1 and ctx.group_host_frames() == 0, "the bench shape groups on the device (K6)"
     want = _oracle_many(oc, frames, False)
     nboxes = 0
     for f in range(B):
@@ -561,6 +564,17 @@ def test_device_grouping_leaves_overflowing_frames_to_the_host(pkg, oracle, synt
     assert ctx.group_host_frames() == B and ctx.last_launch()["device_grouping"] == 0
     for f in range(B):
         assert np.array_equal(got[f], want[f][0])
+    # small batches are latency-bound and grouped on the host by policy (HC_GROUP_MIN_BATCH = 8); the knob moves the bound
+    ctx.set_device_grouping(True)
+    got = ctx.detect_host(frames[:4])
+    assert ctx.group_host_frames() == 4 and ctx.last_launch()["device_grouping"] == 0
+    monkeypatch.setenv("HC_GROUP_MIN_BATCH", "1")
+    ctx1 = pkg.Context(casc)
+    monkeypatch.delenv("HC_GROUP_MIN_BATCH")
+    ctx1.configure(720, 1280, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)
+    got1 = ctx1.detect_host(frames[:1])
+    assert ctx1.group_host_frames() == 0 and ctx1.last_launch()["device_grouping"] == 1
+    assert np.array_equal(got1[0], want[0][0]) and np.array_equal(got[0], want[0][0])
     # minNeighbors 0: the raw rectangles are the result, nothing to group on either side
     ctx0 = pkg.Context(casc)
     ctx0.configure(720, 1280, 1.1, 0, (30, 30), (0, 0), max_batch=B, cand_capacity=1 << 13)

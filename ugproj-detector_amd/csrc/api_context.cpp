@@ -46,6 +46,7 @@ Knobs knobs_from_env() {
   getb("HC_SIDE_PRIO", k.side_prio);
   getb("HC_COPY_PRIO", k.copy_prio);
   getb("HC_DEVICE_GROUP", k.device_group);
+  geti("HC_GROUP_MIN_BATCH", k.group_min_batch, 1, 1 << 20);
   geti("HC_GROUP_BIN_CAP", k.group_bin_cap, 1, HC_GROUP_BIN);
   geti("HC_GROUP_OUT_CAP", k.group_out_cap, 1, HC_GROUP_OUT);
   if (const char* e = getenv("HC_FUSED_MIN_BATCH")) k.fused_min_batch = atof(e);

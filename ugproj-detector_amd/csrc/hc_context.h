@@ -77,6 +77,8 @@ struct Knobs {
   bool copy_prio = true;         // HC_COPY_PRIO=0: the copy stream at normal priority
   int host_threads = 4;          // HC_HOST_THREADS: post-processing threads per context
   bool device_group = true;      // HC_DEVICE_GROUP=0: rectangles are grouped on the host (hc_context_set_device_grouping)
+  int group_min_batch = 8;       // HC_GROUP_MIN_BATCH: batches of fewer frames are grouped on the host (one frame: two more launches and a
+                                 //   one-workgroup sort cost 0.075 ms of latency, the host groups its ~200 rectangles in 0.01; even at 8 frames)
   int group_bin_cap = HC_GROUP_BIN;   // HC_GROUP_BIN_CAP / HC_GROUP_OUT_CAP (tests): raw candidates / grouped boxes per frame beyond
   int group_out_cap = HC_GROUP_OUT;   //   which a frame is left to the host, at most the compiled sizes
 };
