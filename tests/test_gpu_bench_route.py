@@ -582,3 +582,25 @@ def test_device_grouping_leaves_overflowing_frames_to_the_host(pkg, oracle, synt
     assert ctx0.last_launch()["device_grouping"] == 0
     for f in range(B):
         assert np.array_equal(got0[f], want[f][1])
+
+
+def test_device_grouping_survives_a_candidate_overflow(pkg, oracle, synth):
+    """A batch that groups on the device and overflows its raw-candidate workspace: the first pass's grouping saw a
+    truncated list and is discarded with it, the wait grows the workspace and runs the batch -- grouping kernels included --
+    again; boxes and raw candidates of all frames equal the oracle's, and the grown workspace serves the next batch at once."""
+    path = oracle.cascade_path("alt")
+    casc, oc = pkg.Cascade(path), oracle.OracleCascade(path)
+    B = 10
+    frames = np.stack([synth.planted(240, 320, synth.frame_seed(40 + i), nfaces=3, min_size=40, max_size=110)[0] for i in range(B)])
+    ctx = pkg.Context(casc)
+    ctx.configure(240, 320, 1.1, 2, (30, 30), (0, 0), max_batch=B, cand_capacity=4)
+    got = ctx.detect_host(frames)
+    assert ctx.last_launch()["device_grouping"] == 1 and ctx.group_host_frames() == 0
+    raws = ctx.raw_candidates(B)
+    again = ctx.detect_host(frames)
+    nraw = 0
+    for f in range(B):
+        want, raw = oc.detect(frames[f], 1.1, 2, (30, 30))
+        nraw += len(raw)
+        assert np.array_equal(got[f], want) and np.array_equal(raws[f], raw) and np.array_equal(again[f], want), "frame %d" % f
+    assert nraw > 4 * B, "the batch must overflow a workspace of %d candidates (it has %d)" % (4 * B, nraw)

@@ -350,8 +350,9 @@ int enqueue_device(hc_context* c, const uint8_t* d_frames, size_t frame_stride, 
   b.pyr_stride = (size_t)P.pyr_bytes; b.int_stride = (size_t)P.int_words; b.grid_stride = (size_t)P.grid_elems;
   c->timed_last = b.timed;
   // K6: the batch groups its own rectangles unless the raw ones are the result (minNeighbors) or a debug build truncates the cascade
+  // (bins are max_batch x 8 KB: contexts configured for more than 8192 frames per batch keep the host grouping)
   c->group_ran = c->device_group && nframes >= c->k.group_min_batch && group_threshold(c) > 0 && !P.levels.empty() &&
-                 c->k.debug_max_stages == 0;
+                 c->k.debug_max_stages == 0 && c->max_batch <= 8192;
   if (c->group_ran)
     if (int rc = ensure_group(c)) return rc;
   HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int) * (c->group_ran ? 1 + (size_t)nframes : 1), s));
@@ -421,7 +422,7 @@ int hc_debug_enqueue_keys(hc_context* ctx, const unsigned long long* keys, int n
   c->last_launch.nframes = nframes;
   c->strips_ran = false;
   c->timed_last = false;
-  c->group_ran = c->device_group && nframes >= c->k.group_min_batch && hc::group_threshold(c) > 0;
+  c->group_ran = c->device_group && nframes >= c->k.group_min_batch && hc::group_threshold(c) > 0 && c->max_batch <= 8192;
   if (c->group_ran)
     if (int rc = hc::ensure_group(c)) return rc;
   HIPCHK(hipMemsetAsync(c->d_count, 0, sizeof(unsigned int) * (1 + (size_t)nframes), c->stream));
