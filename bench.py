@@ -40,9 +40,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CONFIGS = {
     2: dict(rows=720, cols=1280, cascades=("alt",), batch=512, cpu_sample=256, parity_frames=16,
             label="BASELINE config #2: 1280x720 gray, haarcascade_frontalface_alt"),
-    3: dict(rows=1080, cols=1920, cascades=("alt2", "default"), batch=192, cpu_sample=32, parity_frames=4,
+    3: dict(rows=1080, cols=1920, cascades=("alt2", "default"), batch=384, cpu_sample=32, parity_frames=4,
             label="BASELINE config #3: 1920x1080 gray, haarcascade_frontalface_alt2 + _default on the same frames"),
-    5: dict(rows=2160, cols=3840, cascades=("alt", "alt2", "alt_tree", "default"), batch=64, cpu_sample=8, parity_frames=2,
+    5: dict(rows=2160, cols=3840, cascades=("alt", "alt2", "alt_tree", "default"), batch=128, cpu_sample=8, parity_frames=2,
             label="BASELINE config #5: 3840x2160 gray, all four data/ cascades on the same frames"),
 }
 EXTRA_CONFIGS = (3, 5)         # measured after the headline, a few steps each (`extra.configs`)

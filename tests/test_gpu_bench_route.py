@@ -357,7 +357,7 @@ def test_bench_default_line_has_extra_configs(pkg):
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
     ex = out["extra"]["configs"]
     assert sorted(ex) == ["3", "5"]
-    for k, nf in (("3", 192), ("5", 64)):
+    for k, nf in (("3", 384), ("5", 128)):
         assert "error" not in ex[k], ex[k]
         assert ex[k]["parity"]["bit_exact"] is True and ex[k]["frames_per_step"] == nf
         assert ex[k]["value"] > 0 and 0 < ex[k]["roofline"]["frac"] < 1
