@@ -1,5 +1,6 @@
 #!/bin/bash
-# where k_group_frames spends its time: variants that skip the sort (gs1), the unions (gs2), the whole pair loop (gs4) -- wrong results, timing only
+# where k_group_frames spends its time: variants that skip the sort (gs1), the unions (gs2), the whole pair loop (gs4) -- wrong results, timing only.
+# The variants: apply tools/patches/r4_group_skip.patch, compile csrc/group_kernels.hip with -DHC_GROUP_SKIP=1 / 2 / 4 and link it with the other objects as libhip_cascade_gs<N>.so
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/gparts; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 for v in "" _gs1 _gs2 _gs4; do
   export HC_LIB_PATH=$R/ugproj-detector_amd/libhip_cascade$v.so

@@ -138,9 +138,6 @@ __global__ __launch_bounds__(256) void k_group_frames(const unsigned int* __rest
       const unsigned long long q = keys[j];
       rank += (q < k || (q == k && j < i)) ? 1 : 0;
     }
-#if defined(HC_GROUP_SKIP) && (HC_GROUP_SKIP & 1)
-    rank = i;
-#endif
     sorted[rank] = k;
   }
   __syncthreads();
@@ -173,9 +170,6 @@ __global__ __launch_bounds__(256) void k_group_frames(const unsigned int* __rest
            (double)abs(p.x + p.z - q.x - q.z) <= delta && (double)abs(p.y + p.w - q.y - q.w) <= delta;
   };
   auto unite = [&](int a, int b) {
-#if defined(HC_GROUP_SKIP) && (HC_GROUP_SKIP & 2)
-    if (a >= 0) { tmp[0] = b; return; }
-#endif
     for (;;) {
       a = find_root(parent, a);
       b = find_root(parent, b);
@@ -185,11 +179,7 @@ __global__ __launch_bounds__(256) void k_group_frames(const unsigned int* __rest
       a = hi; b = lo;      // somebody hooked `hi` meanwhile: walk on from there
     }
   };
-#if defined(HC_GROUP_SKIP) && (HC_GROUP_SKIP & 4)
-  for (int i = t; i < 0; i += 256) {
-#else
   for (int i = t; i < n; i += 256) {
-#endif
     const int4 p = rc[i];
     int j = 0;
     for (; j + 4 <= n; j += 4) {
